@@ -1,0 +1,194 @@
+/*
+ * zkgl.h -- C ABI of the MI355X-native Goldilocks/Poseidon/FRI STARK prover backend.
+ *
+ * Drop-in boundary.  The reference reaches this path through one call,
+ *   generate_txn_proof(p_state(), input, None)            /root/reference/ops/src/lib.rs:52
+ * configured by
+ *   AllRecursiveCircuits::new(&AllStark::default(), .., &StarkConfig::standard_fast_config())
+ *                                                         /root/reference/common/src/prover_state/circuit.rs:200-206
+ * and the arithmetic itself lives in the crates pinned at /root/reference/Cargo.lock:3441-3443
+ * (plonky2 0.2.2), :3466-3468 (plonky2_field 0.2.2), :4529-4531 (starky 0.4.0).  Every entry point
+ * below names the upstream item a Rust `-sys` crate would forward to it.
+ *
+ * Conventions
+ *   - every function returns an int32_t status (ZK_OK == 0, negative == error); nothing throws or aborts;
+ *   - a zk_ctx is bound to ONE device and ONE HIP stream; use one ctx per worker thread;
+ *   - field elements are uint64_t; inputs may be non-canonical (in [p, 2^64)), outputs are canonical;
+ *   - extension elements (F_p[x]/(x^2-7)) are two consecutive uint64_t [a0, a1];
+ *   - pointers named d_* are device pointers (HBM), everything else is host memory;
+ *   - polynomials are column-major: column c of an n-row table starts at base + c*n.
+ *   - there is NO CPU fallback: without a usable HIP device zk_ctx_create fails with ZK_ERR_NO_DEVICE.
+ */
+#ifndef ZKGL_H
+#define ZKGL_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_OK 0
+#define ZK_ERR_INVALID_ARG (-1)
+#define ZK_ERR_OOM (-2)
+#define ZK_ERR_HIP (-3)
+#define ZK_ERR_QUOTIENT_DEGREE (-4)   /* upstream: trim_to_len panics "quotient not divisible" */
+#define ZK_ERR_ZERO_INVERSE (-5)      /* upstream: batch_multiplicative_inverse asserts no zeros */
+#define ZK_ERR_POW (-6)               /* no proof-of-work witness in the search window */
+#define ZK_ERR_NO_DEVICE (-7)
+#define ZK_ERR_ZETA_IN_SUBGROUP (-8)  /* upstream: ensure!(zeta^n != 1) */
+#define ZK_ERR_BUFFER_TOO_SMALL (-9)
+
+#define ZK_GOLDILOCKS_P 0xFFFFFFFF00000001ULL
+#define ZK_COSET_SHIFT 14293326489335486720ULL /* F::coset_shift() = MULTIPLICATIVE_GROUP_GENERATOR */
+
+typedef struct zk_ctx zk_ctx;
+typedef struct zk_batch zk_batch;           /* device-resident PolynomialBatch */
+typedef struct zk_challenger zk_challenger; /* device-resident Challenger<F, PoseidonHash> */
+
+/* ------------------------------------------------------------------ context */
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to create a private one. */
+int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out);
+int32_t zk_ctx_destroy(zk_ctx *ctx);
+int32_t zk_ctx_synchronize(zk_ctx *ctx);
+const char *zk_last_error(zk_ctx *ctx);
+/* returns the hipStream_t the ctx enqueues on (for callers that record their own HIP events) */
+void *zk_ctx_stream(zk_ctx *ctx);
+
+/* Per-kernel hipEvent timing on the ctx stream (mirrors upstream's `timed!` scopes that the reference
+ * creates and drops at ops/src/lib.rs:52 via TimingTree::default()).  Off by default. */
+int32_t zk_profile_enable(zk_ctx *ctx, int32_t on);
+int32_t zk_profile_reset(zk_ctx *ctx);
+/* number of distinct kernel names seen; zk_profile_get(i) -> name, launches, total milliseconds */
+int32_t zk_profile_count(zk_ctx *ctx);
+int32_t zk_profile_get(zk_ctx *ctx, int32_t i, const char **name, uint64_t *launches, double *total_ms);
+
+/* Device memory for callers without HIP bindings (Rust side keeps only opaque pointers). */
+int32_t zk_dev_alloc(zk_ctx *ctx, size_t bytes, void **d_ptr);
+int32_t zk_dev_free(zk_ctx *ctx, void *d_ptr);
+int32_t zk_dev_upload(zk_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int32_t zk_dev_download(zk_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
+/* ------------------------------------------------------------------ field / NTT
+ * plonky2_field::fft::{fft_with_options, ifft_with_options}, PolynomialCoeffs::coset_fft_with_options,
+ * PolynomialValues::coset_ifft.  Natural order in, natural order out, in place, n_cols independent columns.
+ *   inverse == 0:  v[i] = sum_j c[j] (shift^j) w_n^{ij}          (shift == 0 or 1: plain FFT)
+ *   inverse == 1:  c[j] = shift^{-j} n^{-1} sum_i v[i] w_n^{-ij}
+ */
+int32_t zk_ntt_batch(zk_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift);
+int32_t zk_ntt_batch_dev(zk_ctx *ctx, uint64_t *d_data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift);
+
+/* ------------------------------------------------------------------ Poseidon
+ * plonky2::hash::poseidon::{Poseidon::poseidon, PoseidonHash::{hash_no_pad, two_to_one}}, hashing::hash_or_noop.
+ */
+int32_t zk_poseidon_permute_batch(zk_ctx *ctx, uint64_t *states /* n x 12 */, size_t n);
+/* rows: n_rows x row_len row-major;  out: n_rows x 4.  hash_or_noop semantics when row_len <= 4. */
+int32_t zk_hash_no_pad_batch(zk_ctx *ctx, const uint64_t *rows, size_t n_rows, uint32_t row_len, uint64_t *out);
+int32_t zk_two_to_one_batch(zk_ctx *ctx, const uint64_t *left, const uint64_t *right, size_t n, uint64_t *out);
+
+/* ------------------------------------------------------------------ Merkle tree over explicit leaves
+ * plonky2::hash::merkle_tree::MerkleTree::new(leaves, cap_height).  leaves: n_leaves x leaf_len row-major (host).
+ * cap_out: 2^cap_height x 4.  digests_out (may be NULL): 2*(n_leaves - 2^cap_height) x 4 in upstream's recursive
+ * layout  left_subtree | left_digest | right_digest | right_subtree  per cap sub-tree.
+ */
+int32_t zk_merkle_build(zk_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint32_t leaf_len, uint32_t cap_height,
+                        uint64_t *cap_out, uint64_t *digests_out);
+
+/* ------------------------------------------------------------------ PolynomialBatch (commit)
+ * plonky2::fri::oracle::PolynomialBatch::{from_values, from_coeffs}(polys, rate_bits, blinding=false, cap_height, ..).
+ * Input: n_cols columns of 2^log_n elements, column-major.  The batch keeps, in HBM: coefficients, the LDE on the
+ * coset g*<w_{2^(log_n+rate_bits)}> in bit-reversed row order (column-major), every Merkle level, and the cap.
+ * cap_out (may be NULL): 2^cap_height x 4, host.
+ */
+int32_t zk_batch_from_values(zk_ctx *ctx, const uint64_t *cols, uint32_t log_n, uint32_t n_cols, uint32_t rate_bits,
+                             uint32_t cap_height, zk_batch **out, uint64_t *cap_out);
+int32_t zk_batch_from_values_dev(zk_ctx *ctx, const uint64_t *d_cols, uint32_t log_n, uint32_t n_cols,
+                                 uint32_t rate_bits, uint32_t cap_height, zk_batch **out, uint64_t *cap_out);
+int32_t zk_batch_from_coeffs(zk_ctx *ctx, const uint64_t *cols, uint32_t log_n, uint32_t n_cols, uint32_t rate_bits,
+                             uint32_t cap_height, zk_batch **out, uint64_t *cap_out);
+int32_t zk_batch_from_coeffs_dev(zk_ctx *ctx, const uint64_t *d_cols, uint32_t log_n, uint32_t n_cols,
+                                 uint32_t rate_bits, uint32_t cap_height, zk_batch **out, uint64_t *cap_out);
+int32_t zk_batch_free(zk_batch *b);
+int32_t zk_batch_info(const zk_batch *b, uint32_t *log_n, uint32_t *n_cols, uint32_t *rate_bits, uint32_t *cap_height);
+int32_t zk_batch_get_cap(zk_batch *b, uint64_t *cap_out);
+/* PolynomialBatch::get_lde_values(index, step) for each idx[i]: out[i*n_cols .. ] = leaves[bitrev(idx[i]*step)] */
+int32_t zk_batch_get_lde_rows(zk_batch *b, const uint32_t *idx, uint32_t n_idx, uint32_t step, uint64_t *out);
+/* raw leaf `leaf_idx` (already bit-reversed numbering, as FRI queries use it): n_cols elements */
+int32_t zk_batch_get_leaf(zk_batch *b, uint32_t leaf_idx, uint64_t *out);
+/* MerkleTree::prove(leaf_idx): (log_n + rate_bits - cap_height) x 4 siblings, leaf level first */
+int32_t zk_batch_merkle_prove(zk_batch *b, uint32_t leaf_idx, uint64_t *siblings_out);
+/* MerkleTree::digests in upstream's recursive layout: 2*(2^(log_n+rate_bits) - 2^cap_height) x 4 */
+int32_t zk_batch_get_digests(zk_batch *b, uint64_t *digests_out);
+/* polynomials[col].coeffs, natural order, 2^log_n elements */
+int32_t zk_batch_get_coeffs(zk_batch *b, uint32_t col, uint64_t *out);
+/* PolynomialCoeffs::to_extension().eval(point) for every column: out = n_cols x 2 */
+int32_t zk_batch_eval_at(zk_batch *b, const uint64_t point[2], uint64_t *out);
+
+/* ------------------------------------------------------------------ Challenger (device-resident transcript)
+ * plonky2::iop::challenger::Challenger<F, PoseidonHash>.  The sponge state lives in HBM and is advanced by a
+ * one-wave kernel, so a whole proof can be enqueued without host round trips; these entry points are the
+ * (synchronous) host view of the same object.
+ */
+int32_t zk_challenger_new(zk_ctx *ctx, zk_challenger **out);
+int32_t zk_challenger_free(zk_challenger *ch);
+int32_t zk_challenger_observe(zk_challenger *ch, const uint64_t *elems, uint32_t n);
+int32_t zk_challenger_get(zk_challenger *ch, uint32_t n, uint64_t *out);
+int32_t zk_challenger_compact(zk_challenger *ch, uint64_t out_state[12]);
+
+/* ------------------------------------------------------------------ AIR description (plain data)
+ * Stand-in for a starky `Stark::eval_packed_generic` body: a straight-line program over
+ * the base field evaluated at every point of the LDE coset.  Operand = kind<<24 | index.
+ */
+enum {
+    ZK_OPND_REG = 0,       /* temporary register */
+    ZK_OPND_LOCAL = 1,     /* vars.local_values[i]; i >= n_trace_cols addresses auxiliary column i - n_trace_cols */
+    ZK_OPND_NEXT = 2,      /* vars.next_values[i], same indexing */
+    ZK_OPND_CONST = 3,     /* air->constants[i] */
+    ZK_OPND_PUBLIC = 4,    /* public_inputs[i] */
+    ZK_OPND_CHALLENGE = 5  /* lookup/CTL challenges: [beta_0, gamma_0, beta_1, gamma_1, ...] */
+};
+enum {
+    ZK_OP_ADD = 0, ZK_OP_SUB = 1, ZK_OP_MUL = 2,
+    /* ConstraintConsumer::{constraint, constraint_transition, constraint_first_row, constraint_last_row}(a) */
+    ZK_OP_EMIT = 3, ZK_OP_EMIT_TRANSITION = 4, ZK_OP_EMIT_FIRST = 5, ZK_OP_EMIT_LAST = 6
+};
+#define ZK_OPND(kind, idx) (((uint32_t)(kind) << 24) | (uint32_t)(idx))
+typedef struct { uint32_t op, dst, a, b; } zk_instr;
+
+/* One logUp/CTL-shaped helper column (starky::lookup / cross_table_lookup::partial_sums):
+ *   h[row] = 1/(t[a0] + beta*t[b0] + gamma) + 1/(t[a1] + beta*t[b1] + gamma)        (t = trace columns)
+ * For every challenge set j the auxiliary columns are  [h_0 .. h_{H-1}, Z]  with the suffix sum
+ *   Z[row] = sum_{s >= row} sum_m h_m[s].                                                            */
+typedef struct { uint32_t a0, b0, a1, b1; } zk_helper_desc;
+
+typedef struct {
+    uint32_t n_trace_cols;
+    uint32_t n_public_inputs;
+    uint32_t n_helpers;        /* H; auxiliary columns = num_challenges * (H + 1), or 0 when H == 0 */
+    uint32_t n_constants;
+    uint32_t n_regs;
+    uint32_t n_instrs;
+    uint32_t constraint_degree; /* 3 for every zkEVM table -> quotient_degree_factor 2 */
+    uint32_t reserved;
+    const zk_helper_desc *helpers;
+    const uint64_t *constants;
+    const zk_instr *instrs;
+} zk_air;
+
+/* starky::config::StarkConfig; zk_stark_config_standard_fast() == StarkConfig::standard_fast_config() */
+typedef struct {
+    uint32_t security_bits;        /* 100 */
+    uint32_t num_challenges;       /* 2 */
+    uint32_t rate_bits;            /* 1 */
+    uint32_t cap_height;           /* 4 */
+    uint32_t proof_of_work_bits;   /* 16 */
+    uint32_t fri_arity_bits;       /* ConstantArityBits(4, 5) */
+    uint32_t fri_final_poly_bits;  /* 5 */
+    uint32_t num_query_rounds;     /* 84 */
+} zk_stark_config;
+void zk_stark_config_standard_fast(zk_stark_config *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKGL_H */

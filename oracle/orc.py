@@ -1,0 +1,243 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE (tests/, smoke(), bench.py cpu_baseline only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_here = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    so = os.path.join(_here, "liboracle.so")
+    srcs = [os.path.join(_here, f) for f in ("prims.c", "stark.c", "verify.c", "gl.h", "oracle.h", "poseidon_constants.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _here, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        L = _lib
+        L.orc_gl_mul.restype = C.c_uint64
+        L.orc_gl_mul.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_gl_inv.restype = C.c_uint64
+        L.orc_gl_inv.argtypes = [C.c_uint64]
+        L.orc_gl_root.restype = C.c_uint64
+        L.orc_gl_root.argtypes = [C.c_uint32]
+        L.orc_batch_from_values.restype = C.c_void_p
+        L.orc_batch_from_coeffs.restype = C.c_void_p
+        for f in ("orc_batch_cap", "orc_batch_leaves", "orc_batch_coeffs", "orc_batch_digests"):
+            getattr(L, f).restype = u64p
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.orc_batch_free.argtypes = [C.c_void_p]
+        L.orc_batch_prove.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_batch_eval_at.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_proof_size_words.restype = C.c_size_t
+        L.orc_challenger_get.restype = C.c_uint64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def poseidon(state):
+    s = u64(state).copy()
+    lib().orc_poseidon(_p(s))
+    return s
+
+
+def poseidon_batch(states):
+    s = u64(states).copy()
+    lib().orc_poseidon_batch(_p(s), C.c_size_t(s.size // 12))
+    return s
+
+
+def hash_rows(rows):
+    rows = u64(rows)
+    out = np.empty((rows.shape[0], 4), dtype=np.uint64)
+    lib().orc_hash_rows(_p(rows), C.c_size_t(rows.shape[0]), C.c_uint32(rows.shape[1]), _p(out))
+    return out
+
+
+def two_to_one(l, r):
+    l, r = u64(l), u64(r)
+    out = np.empty_like(l)
+    for i in range(l.reshape(-1, 4).shape[0]):
+        lib().orc_two_to_one(_p(l.reshape(-1, 4)[i]), _p(r.reshape(-1, 4)[i]), C.c_void_p(out.ctypes.data + 32 * i))
+    return out
+
+
+def fft(cols, inverse=False, shift=0):
+    """cols: (n_cols, n) -- natural order in/out."""
+    a = u64(cols).copy()
+    a2 = a.reshape(-1, a.shape[-1])
+    log_n = a2.shape[1].bit_length() - 1
+    lib().orc_fft(_p(a2), C.c_uint32(log_n), C.c_uint32(a2.shape[0]), C.c_int32(1 if inverse else 0), C.c_uint64(shift))
+    return a
+
+
+def merkle_build(leaves, cap_height):
+    leaves = u64(leaves)
+    L, ll = leaves.shape
+    cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+    dig = np.empty((max(1, 2 * (L - (1 << cap_height))), 4), dtype=np.uint64)
+    rc = lib().orc_merkle_build(_p(leaves), C.c_size_t(L), C.c_uint32(ll), C.c_uint32(cap_height), _p(cap), _p(dig))
+    assert rc == 0
+    return cap, dig[:2 * (L - (1 << cap_height))]
+
+
+def merkle_prove(leaves, cap_height, idx):
+    leaves = u64(leaves)
+    L, ll = leaves.shape
+    ns = (L.bit_length() - 1) - cap_height
+    sib = np.empty((max(ns, 1), 4), dtype=np.uint64)
+    rc = lib().orc_merkle_prove(_p(leaves), C.c_size_t(L), C.c_uint32(ll), C.c_uint32(cap_height), C.c_uint32(idx), _p(sib))
+    assert rc == 0
+    return sib[:ns]
+
+
+def merkle_verify(leaf, idx, sib, cap):
+    leaf, sib, cap = u64(leaf), u64(sib), u64(cap)
+    return lib().orc_merkle_verify(_p(leaf), C.c_uint32(leaf.size), C.c_uint32(idx), _p(sib), C.c_uint32(sib.size // 4), _p(cap)) == 0
+
+
+class Challenger:
+    class _S(C.Structure):
+        _fields_ = [("state", C.c_uint64 * 12), ("inbuf", C.c_uint64 * 8), ("outbuf", C.c_uint64 * 8),
+                    ("n_in", C.c_uint32), ("n_out", C.c_uint32)]
+
+    def __init__(self):
+        self.s = self._S()
+        lib().orc_challenger_init(C.byref(self.s))
+
+    def observe(self, xs):
+        xs = u64(np.atleast_1d(xs)).ravel()
+        lib().orc_challenger_observe(C.byref(self.s), _p(xs), C.c_uint32(xs.size))
+
+    def get(self, n=1):
+        out = np.empty(n, dtype=np.uint64)
+        lib().orc_challenger_get_n(C.byref(self.s), C.c_uint32(n), _p(out))
+        return out
+
+    def compact(self):
+        out = np.empty(12, dtype=np.uint64)
+        lib().orc_challenger_compact(C.byref(self.s), _p(out))
+        return out
+
+
+class Batch:
+    """orc_batch wrapper: PolynomialBatch::from_values / from_coeffs."""
+
+    def __init__(self, cols, rate_bits=1, cap_height=4, from_coeffs=False):
+        cols = u64(cols)
+        self.n_cols, n = cols.shape
+        self.log_n = n.bit_length() - 1
+        self.rate_bits, self.cap_height = rate_bits, cap_height
+        f = lib().orc_batch_from_coeffs if from_coeffs else lib().orc_batch_from_values
+        self.h = C.c_void_p(f(_p(cols), C.c_uint32(self.log_n), C.c_uint32(self.n_cols), C.c_uint32(rate_bits), C.c_uint32(cap_height)))
+        self.L = n << rate_bits
+
+    def _arr(self, ptr, shape):
+        return np.ctypeslib.as_array(ptr, shape=shape).copy()
+
+    @property
+    def cap(self):
+        return self._arr(lib().orc_batch_cap(self.h), (1 << self.cap_height, 4))
+
+    @property
+    def leaves(self):
+        return self._arr(lib().orc_batch_leaves(self.h), (self.L, self.n_cols))
+
+    @property
+    def coeffs(self):
+        return self._arr(lib().orc_batch_coeffs(self.h), (self.n_cols, 1 << self.log_n))
+
+    @property
+    def digests(self):
+        nd = 2 * (self.L - (1 << self.cap_height))
+        return self._arr(lib().orc_batch_digests(self.h), (nd, 4)) if nd else np.empty((0, 4), np.uint64)
+
+    def prove(self, idx):
+        ns = self.log_n + self.rate_bits - self.cap_height
+        sib = np.empty((max(ns, 1), 4), dtype=np.uint64)
+        lib().orc_batch_prove(self.h, C.c_uint32(idx), _p(sib))
+        return sib[:ns]
+
+    def eval_at(self, point):
+        pt = u64(point)
+        out = np.empty((self.n_cols, 2), dtype=np.uint64)
+        lib().orc_batch_eval_at(self.h, _p(pt), _p(out))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_batch_free(self.h)
+            self.h = None
+
+
+class Table(C.Structure):
+    _fields_ = [("air", C.c_void_p), ("log_n", C.c_uint32), ("reserved", C.c_uint32), ("trace", C.c_void_p),
+                ("public_inputs", C.c_void_p)]
+
+
+def synth_trace(n_cols, log_n, seed):
+    t = np.empty((n_cols, 1 << log_n), dtype=np.uint64)
+    pub = np.empty(3, dtype=np.uint64)
+    lib().orc_synth_trace(C.c_uint32(n_cols), C.c_uint32(log_n), C.c_uint64(seed), _p(t), _p(pub))
+    return t, pub
+
+
+def aux_columns(air_prog, challenges, trace, num_challenges=2):
+    trace = u64(trace)
+    log_n = trace.shape[1].bit_length() - 1
+    aux = np.empty((air_prog.n_aux_cols, trace.shape[1]), dtype=np.uint64)
+    ch = u64(challenges)
+    rc = lib().orc_aux_columns(air_prog.ref, C.c_uint32(num_challenges), _p(ch), _p(trace), C.c_uint32(log_n), _p(aux))
+    return rc, aux
+
+
+def _tables(items):
+    """items: list of (AirProgram, log_n, trace or None, public_inputs)."""
+    arr = (Table * len(items))()
+    keep = []
+    for i, (prog, log_n, trace, pub) in enumerate(items):
+        pub = u64(pub)
+        keep.append(pub)
+        arr[i].air = C.cast(prog.ref, C.c_void_p)
+        arr[i].log_n = log_n
+        if trace is not None:
+            trace = u64(trace)
+            keep.append(trace)
+            arr[i].trace = trace.ctypes.data
+        arr[i].public_inputs = pub.ctypes.data
+    return arr, keep
+
+
+def prove(cfg, items):
+    arr, keep = _tables(items)
+    cap = lib().orc_proof_size_words(C.byref(cfg), C.c_uint32(len(items)), arr)
+    out = np.zeros(cap, dtype=np.uint64)
+    n = C.c_size_t(0)
+    rc = lib().orc_prove(C.byref(cfg), C.c_uint32(len(items)), arr, _p(out), C.c_size_t(cap), C.byref(n))
+    return rc, out[:n.value]
+
+
+def verify(cfg, items, proof):
+    arr, keep = _tables(items)
+    proof = u64(proof)
+    return lib().orc_verify(C.byref(cfg), C.c_uint32(len(items)), arr, _p(proof), C.c_size_t(proof.size))
+
+
+def proof_size_words(cfg, items):
+    arr, keep = _tables(items)
+    return lib().orc_proof_size_words(C.byref(cfg), C.c_uint32(len(items)), arr)

@@ -1,0 +1,372 @@
+"""Pure-Python restatement of the upstream primitives (TEST INFRASTRUCTURE ONLY).
+
+This file is part of the oracle: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import it.  The product never does.
+
+Source of truth: SURVEY.md Appendix A, which restates the un-vendored crates
+pinned by /root/reference/Cargo.lock:3441-3443 (plonky2 0.2.2),
+:3466-3468 (plonky2_field 0.2.2) and :4529-4531 (starky 0.4.0), reached from
+the reference at ops/src/lib.rs:52 (generate_txn_proof).
+
+Parity status
+  * externally anchored: Goldilocks constants, the 360 Poseidon round
+    constants (sha256 below), the four upstream Poseidon `test_vectors` KATs.
+  * everything above the permutation (sponge mode, Merkle layout, challenger,
+    FRI) is a recalled spec: "parity unpinned" (SURVEY.md section 8c).
+
+Pure-Python loops: use for small cases only.
+"""
+import hashlib
+import struct
+
+P = 0xFFFFFFFF00000001
+EPS = 0xFFFFFFFF
+MULTIPLICATIVE_GROUP_GENERATOR = 14293326489335486720  # = coset shift  (A1)
+POWER_OF_TWO_GENERATOR = 7277203076849721926           # order 2^32     (A1)
+TWO_ADICITY = 32
+W_EXT = 7                                              # ext2: x^2 = 7   (A1)
+
+# ---------------------------------------------------------------- field (A1)
+
+def add(a, b): return (a + b) % P
+def sub(a, b): return (a - b) % P
+def mul(a, b): return (a * b) % P
+def inv(a): return pow(a, P - 2, P)
+
+
+def root_of_unity(k):
+    """primitive_root_of_unity(k) = POWER_OF_TWO_GENERATOR^(2^(32-k))  (A1)"""
+    assert 0 <= k <= TWO_ADICITY
+    return pow(POWER_OF_TWO_GENERATOR, 1 << (TWO_ADICITY - k), P)
+
+
+def ext_mul(a, b):
+    """(a0+a1 x)(b0+b1 x) with x^2 = 7  (A1)"""
+    return ((a[0] * b[0] + W_EXT * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def ext_add(a, b): return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+def ext_sub(a, b): return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+
+
+def ext_inv(a):
+    # (a0 + a1 x)^-1 = (a0 - a1 x) / (a0^2 - 7 a1^2)
+    d = inv((a[0] * a[0] - W_EXT * a[1] * a[1]) % P)
+    return (a[0] * d % P, (P - a[1]) * d % P)
+
+
+def ext_pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = ext_mul(r, a)
+        a = ext_mul(a, a)
+        e >>= 1
+    return r
+
+# ------------------------------------------------ ChaCha8Rng(seed_from_u64(0)) (A2)
+
+
+def _pcg32_seed_bytes(state):
+    """rand_core::SeedableRng::seed_from_u64: 8 PCG32 outputs -> 32-byte key."""
+    MUL, INC = 6364136223846793005, 11634580027462260723
+    out = b""
+    for _ in range(8):
+        state = (state * MUL + INC) & 0xFFFFFFFFFFFFFFFF
+        xs = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF
+        rot = state >> 59
+        x = ((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF
+        out += struct.pack("<I", x)
+    return out
+
+
+def _chacha_block(key_words, counter, rounds):
+    def rotl(v, n): return ((v << n) | (v >> (32 - n))) & 0xFFFFFFFF
+    st = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key_words) + [
+        counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF, 0, 0]
+    x = list(st)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = rotl(x[b] ^ x[c], 7)
+    for _ in range(rounds // 2):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(x[i] + st[i]) & 0xFFFFFFFF for i in range(16)]
+
+
+def chacha8_u64_stream(seed_u64):
+    key = struct.unpack("<8I", _pcg32_seed_bytes(seed_u64))
+    counter = 0
+    while True:
+        blk = _chacha_block(key, counter, 8)
+        counter += 1
+        for i in range(0, 16, 2):
+            yield blk[i] | (blk[i + 1] << 32)
+
+
+def poseidon_round_constants():
+    """360 x gen_range(0..p) from ChaCha8Rng::seed_from_u64(0)  (A2)."""
+    out = []
+    s = chacha8_u64_stream(0)
+    while len(out) < 360:
+        v = next(s)
+        m = v * P
+        if (m & 0xFFFFFFFFFFFFFFFF) <= P - 1:
+            out.append(m >> 64)
+    return out
+
+
+RC_SHA256 = "d2fcbb5be293c50ab4b1ddcd9c81005b12d689816a54c91a054f97f6588a20a8"
+
+# ----------------------------------------------------------- Poseidon (A2)
+WIDTH, RATE, CAP = 12, 8, 4
+N_FULL_HALF, N_PARTIAL = 4, 22
+MDS_CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+MDS_DIAG = [8] + [0] * 11
+_RC = None
+
+
+def rc():
+    global _RC
+    if _RC is None:
+        _RC = poseidon_round_constants()
+        h = hashlib.sha256(b"".join(struct.pack("<Q", c) for c in _RC)).hexdigest()
+        assert h == RC_SHA256, h
+    return _RC
+
+
+def mds_matrix():
+    """M[r][c] such that out[r] = sum_c M[r][c] s[c]  (A2)."""
+    return [[(MDS_CIRC[(c - r) % 12] + (MDS_DIAG[r] if r == c else 0)) for c in range(12)]
+            for r in range(12)]
+
+
+def _mds(s):
+    return [(sum(s[(i + r) % 12] * MDS_CIRC[i] for i in range(12)) + s[r] * MDS_DIAG[r]) % P
+            for r in range(12)]
+
+
+def poseidon(state):
+    """Naive permutation: 4 full + 22 partial + 4 full, x^7  (A2)."""
+    RC = rc()
+    s = [x % P for x in state]
+    r = 0
+    for phase, n in ((0, N_FULL_HALF), (1, N_PARTIAL), (0, N_FULL_HALF)):
+        for _ in range(n):
+            s = [(s[i] + RC[12 * r + i]) % P for i in range(12)]
+            if phase == 0:
+                s = [pow(x, 7, P) for x in s]
+            else:
+                s[0] = pow(s[0], 7, P)
+            s = _mds(s)
+            r += 1
+    return s
+
+
+KATS = [
+    ([0] * 12,
+     "3c18a9786cb0b359 c4055e3364a246c3 7953db0ab48808f4 c71603f33a1144ca d7709673896996dc 46a84e87642f44ed "
+     "d032648251ee0b3c 1c687363b207df62 df8565563e8045fe 40f5b37ff4254dae d070f637b431067c 1792b1c4342109d7"),
+    (list(range(12)),
+     "d64e1e3efc5b8e9e 53666633020aaa47 d40285597c6a8825 613a4f81e81231d2 414754bfebd051f0 cb1f8980294a023f "
+     "6eb2a9e4d54a9d0f 1902bc3af467e056 f045d5eafdc6021f e4150f77caaa3be5 c9bfd01d39b50cce 5c0a27fcb0e1459b"),
+    ([P - 1] * 12,
+     "be0085cfc57a8357 d95af71847d05c09 cf55a13d33c1c953 95803a74f4530e82 fcd99eb30a135df1 e095905e913a3029 "
+     "de0392461b42919b 7d3260e24e81d031 10d3d0465d9deaa0 a87571083dfc2a47 e18263681e9958f8 e28e96f1ae5e60d3"),
+    ([int(x, 16) for x in
+      "8ccbbbea4fe5d2b7 c2af59ee9ec49970 90f7e1a9e658446a dcc0630a3ab8b1b8 7ff8256bca20588c 5d99a7ca0c44ecfb "
+      "48452b17a70fbee3 eb09d654690b6c88 4a55d3a39c676a88 c0407a38d2285139 a234bac9356386d1 e1633f2bad98a52f".split()],
+     "a89280105650c4ec ab542d53860d12ed 5704148e9ccab94f d3a826d4b62da9f5 8a7a6ca87892574f c7017e1cad1a674e "
+     "1f06668922318e34 a3b203bc8102676f fcc781b0ce382bf2 934c69ff3ed14ba5 504688a5996e8f13 401f3f2ed524a2ba"),
+]
+
+# ------------------------------------------------------- sponge / compression (A4)
+
+
+def hash_no_pad(x):
+    st = [0] * 12
+    for off in range(0, len(x), RATE):
+        chunk = x[off:off + RATE]
+        st[:len(chunk)] = [c % P for c in chunk]
+        st = poseidon(st)
+    return st[:4]
+
+
+def hash_or_noop(x):
+    if len(x) <= 4:
+        return [c % P for c in x] + [0] * (4 - len(x))
+    return hash_no_pad(x)
+
+
+def two_to_one(l, r):
+    return poseidon(list(l) + list(r) + [0] * 4)[:4]
+
+# ------------------------------------------------------------- FFT / LDE (A3)
+
+
+def bitrev(i, bits):
+    r = 0
+    for _ in range(bits):
+        r = (r << 1) | (i & 1)
+        i >>= 1
+    return r
+
+
+def fft(c):
+    n = len(c)
+    k = n.bit_length() - 1
+    assert 1 << k == n
+    a = [c[bitrev(i, k)] % P for i in range(n)]
+    m = 1
+    while m < n:
+        w_m = root_of_unity((2 * m).bit_length() - 1)
+        for s in range(0, n, 2 * m):
+            w = 1
+            for j in range(m):
+                u, v = a[s + j], a[s + j + m] * w % P
+                a[s + j], a[s + j + m] = (u + v) % P, (u - v) % P
+                w = w * w_m % P
+        m *= 2
+    return a
+
+
+def ifft(v):
+    n = len(v)
+    ninv = inv(n)
+    f = fft(v)
+    return [f[(n - i) % n] * ninv % P for i in range(n)]
+
+
+def coset_fft(c, shift):
+    s, out = 1, []
+    for x in c:
+        out.append(x * s % P)
+        s = s * shift % P
+    return fft(out)
+
+
+def coset_ifft(v, shift):
+    c = ifft(v)
+    sinv, s, out = inv(shift), 1, []
+    for x in c:
+        out.append(x * s % P)
+        s = s * sinv % P
+    return out
+
+
+def lde_values(coeffs, rate_bits):
+    """PolynomialCoeffs::lde(rate_bits).coset_fft(g)  (A3)"""
+    n = len(coeffs)
+    return coset_fft(list(coeffs) + [0] * (n * ((1 << rate_bits) - 1)), MULTIPLICATIVE_GROUP_GENERATOR)
+
+# -------------------------------------------------------------- Merkle (A5)
+
+
+def merkle_tree(leaves, cap_height):
+    """Returns (cap, digests) with plonky2's recursive digest layout (A5)."""
+    L = len(leaves)
+    lg = L.bit_length() - 1
+    assert 1 << lg == L and cap_height <= lg
+    hashes = [hash_or_noop(l) for l in leaves]
+    if cap_height == lg:
+        return hashes, []
+    ncap = 1 << cap_height
+    sub = L // ncap
+
+    def build(hs):
+        # returns (root, buffer) ; buffer = left_buf | left_digest | right_digest | right_buf
+        if len(hs) == 1:
+            return hs[0], []
+        h = len(hs) // 2
+        lroot, lbuf = build(hs[:h])
+        rroot, rbuf = build(hs[h:])
+        return two_to_one(lroot, rroot), lbuf + [lroot, rroot] + rbuf
+    cap, digests = [], []
+    for i in range(ncap):
+        root, buf = build(hashes[i * sub:(i + 1) * sub])
+        cap.append(root)
+        digests += buf
+    return cap, digests
+
+
+def merkle_prove(leaves, cap_height, idx):
+    """Sibling path from the leaf level up to (not including) the cap level (A5)."""
+    L = len(leaves)
+    lg = L.bit_length() - 1
+    level = [hash_or_noop(l) for l in leaves]
+    sibs = []
+    for _ in range(lg - cap_height):
+        sibs.append(level[idx ^ 1])
+        level = [two_to_one(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
+        idx >>= 1
+    return sibs
+
+
+def merkle_verify(leaf, idx, sibs, cap):
+    cur = hash_or_noop(leaf)
+    for s in sibs:
+        cur = two_to_one(s, cur) if idx & 1 else two_to_one(cur, s)
+        idx >>= 1
+    return cur == list(cap[idx])
+
+# ---------------------------------------------------------- Challenger (A6)
+
+
+class Challenger:
+    def __init__(self):
+        self.state = [0] * 12
+        self.inp = []
+        self.out = []
+
+    def observe(self, x):
+        self.out = []
+        self.inp.append(x % P)
+        if len(self.inp) == RATE:
+            self._duplex()
+
+    def observe_many(self, xs):
+        for x in xs:
+            self.observe(x)
+
+    def observe_cap(self, cap):
+        for h in cap:
+            self.observe_many(h)
+
+    def observe_ext(self, e):
+        self.observe(e[0]); self.observe(e[1])
+
+    def _duplex(self):
+        self.state[:len(self.inp)] = self.inp
+        self.inp = []
+        self.state = poseidon(self.state)
+        self.out = list(self.state[:RATE])
+
+    def get(self):
+        if self.inp or not self.out:
+            self._duplex()
+        return self.out.pop()
+
+    def get_n(self, n):
+        return [self.get() for _ in range(n)]
+
+    def get_ext(self):
+        a = self.get(); b = self.get()
+        return (a, b)
+
+    def compact(self):
+        if self.inp:
+            self._duplex()
+        self.out = []
+        return list(self.state)
+
+
+def fri_reduction_arity_bits(degree_bits, rate_bits=1, cap_height=4, arity_bits=4, final_poly_bits=5):
+    """ConstantArityBits(4,5) schedule (A8)."""
+    out, d = [], degree_bits
+    while d > final_poly_bits and d + rate_bits - arity_bits >= cap_height:
+        out.append(arity_bits)
+        d -= arity_bits
+    return out
