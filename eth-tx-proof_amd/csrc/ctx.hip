@@ -1,0 +1,167 @@
+// Context, stream-ordered caching allocator, per-kernel hipEvent profiler, device-memory helpers.
+// Boundary: include/zkgl.h "context" group.  One ctx = one device + one HIP stream = one worker thread of the
+// reference's runtime (paladin `--num-workers N`, /root/reference/README.md:60-63).
+#include "zk_internal.h"
+
+void *zk_ctx::alloc(size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_blocks.lower_bound(bytes);
+    if (it != free_blocks.end() && it->first <= bytes + bytes / 8) {
+        void *p = it->second;
+        free_blocks.erase(it);
+        return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // give cached blocks back to the driver and retry once
+        for (auto &kv : free_blocks) { hipFree(kv.second); block_size.erase(kv.second); bytes_allocated -= kv.first; }
+        free_blocks.clear();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return nullptr; }
+    }
+    block_size[p] = bytes;
+    bytes_allocated += bytes;
+    return p;
+}
+
+void zk_ctx::release(void *p) {
+    if (!p) return;
+    auto it = block_size.find(p);
+    if (it == block_size.end()) return;
+    free_blocks.emplace(it->second, p);
+}
+
+ProfScope::ProfScope(zk_ctx *c, const char *name) : ctx(c), idx(-1), e0(nullptr), e1(nullptr) {
+    if (!c->prof) return;
+    auto it = c->prof_index.find(name);
+    if (it == c->prof_index.end()) {
+        idx = (int)c->prof_recs.size();
+        c->prof_index[name] = idx;
+        c->prof_recs.emplace_back();
+        c->prof_recs.back().name = name;
+    } else idx = it->second;
+    auto get = [&]() {
+        if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+        hipEvent_t e; hipEventCreate(&e); return e;
+    };
+    e0 = get(); e1 = get();
+    hipEventRecord(e0, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (idx < 0) return;
+    hipEventRecord(e1, ctx->stream);
+    ctx->prof_recs[idx].pending.emplace_back(e0, e1);
+    ctx->prof_recs[idx].launches++;
+}
+void zk_ctx::prof_flush() {
+    for (auto &r : prof_recs) {
+        for (auto &pr : r.pending) {
+            float ms = 0.f;
+            hipEventSynchronize(pr.second);
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            r.total_ms += ms;
+            event_pool.push_back(pr.first); event_pool.push_back(pr.second);
+        }
+        r.pending.clear();
+    }
+}
+
+extern "C" {
+
+int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
+    if (!out) return ZK_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZK_ERR_NO_DEVICE;   // no CPU fallback
+    if (device < 0 || device >= count) return ZK_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return ZK_ERR_HIP;
+    zk_ctx *c = new zk_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZK_ERR_HIP; }
+        c->own_stream = true;
+    }
+    if (hipMalloc((void **)&c->d_err, 256) != hipSuccess) { delete c; return ZK_ERR_OOM; }
+    hipMemsetAsync(c->d_err, 0, 256, c->stream);
+    *out = c;
+    return ZK_OK;
+}
+
+int32_t zk_ctx_destroy(zk_ctx *c) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    c->prof_flush();
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    for (auto &kv : c->block_size) hipFree(kv.first);
+    hipFree(c->d_err);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return ZK_OK;
+}
+
+int32_t zk_ctx_synchronize(zk_ctx *c) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+const char *zk_last_error(zk_ctx *c) { return c ? c->last_error.c_str() : "null ctx"; }
+void *zk_ctx_stream(zk_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int32_t zk_profile_enable(zk_ctx *c, int32_t on) { if (!c) return ZK_ERR_INVALID_ARG; c->prof = on != 0; return ZK_OK; }
+int32_t zk_profile_reset(zk_ctx *c) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    hipStreamSynchronize(c->stream);
+    c->prof_flush();
+    c->prof_recs.clear(); c->prof_index.clear();
+    return ZK_OK;
+}
+int32_t zk_profile_count(zk_ctx *c) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    hipStreamSynchronize(c->stream);
+    c->prof_flush();
+    return (int32_t)c->prof_recs.size();
+}
+int32_t zk_profile_get(zk_ctx *c, int32_t i, const char **name, uint64_t *launches, double *total_ms) {
+    if (!c || i < 0 || i >= (int32_t)c->prof_recs.size()) return ZK_ERR_INVALID_ARG;
+    if (name) *name = c->prof_recs[i].name.c_str();
+    if (launches) *launches = c->prof_recs[i].launches;
+    if (total_ms) *total_ms = c->prof_recs[i].total_ms;
+    return ZK_OK;
+}
+
+int32_t zk_dev_alloc(zk_ctx *c, size_t bytes, void **d_ptr) {
+    if (!c || !d_ptr) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    *d_ptr = c->alloc(bytes);
+    return *d_ptr ? ZK_OK : ZK_ERR_OOM;
+}
+int32_t zk_dev_free(zk_ctx *c, void *d_ptr) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    c->release(d_ptr);
+    return ZK_OK;
+}
+int32_t zk_dev_upload(zk_ctx *c, void *d_dst, const void *src, size_t bytes) {
+    if (!c || (!d_dst && bytes) || (!src && bytes)) return ZK_ERR_INVALID_ARG;
+    HIP_TRY(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+int32_t zk_dev_download(zk_ctx *c, void *dst, const void *d_src, size_t bytes) {
+    if (!c || (!dst && bytes) || (!d_src && bytes)) return ZK_ERR_INVALID_ARG;
+    HIP_TRY(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+void zk_stark_config_standard_fast(zk_stark_config *c) {
+    if (!c) return;
+    c->security_bits = 100; c->num_challenges = 2; c->rate_bits = 1; c->cap_height = 4;
+    c->proof_of_work_bits = 16; c->fri_arity_bits = 4; c->fri_final_poly_bits = 5; c->num_query_rounds = 84;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Goldilocks field arithmetic for gfx950 device code (and the few host-side table builders).
+// F_p, p = 2^64 - 2^32 + 1; ext2 = F_p[x]/(x^2 - 7).  Mirrors plonky2_field 0.2.2 goldilocks_field.rs /
+// extension/quadratic.rs (crate pinned at /root/reference/Cargo.lock:3466-3468; spec: SURVEY.md A1).
+// Invariant: every value stored to memory is canonical (< p).  add/sub/mul take canonical inputs and
+// return canonical outputs; gl_canon() is applied once where caller-supplied data enters.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+#define GL_P 0xFFFFFFFF00000001ULL
+#define GL_EPS 0xFFFFFFFFULL
+#define GL_GEN 14293326489335486720ULL
+#define GL_POW2_GEN 7277203076849721926ULL
+
+#define GLD __host__ __device__ __forceinline__
+
+GLD u64 gl_canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
+
+GLD u64 gl_add(u64 a, u64 b) {
+    u64 s = a + b;
+    // carry: true sum = s + 2^64 = s + eps (mod p), and s + eps < p here; no carry: at most one subtraction of p
+    if (s < a) return s + GL_EPS;
+    return s >= GL_P ? s - GL_P : s;
+}
+GLD u64 gl_sub(u64 a, u64 b) {
+    u64 d = a - b;
+    return a < b ? d - GL_EPS : d;   // borrow: d + p = d - eps (mod 2^64)
+}
+GLD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+GLD u64 gl_dbl(u64 a) { return gl_add(a, a); }
+
+// reduce a 128-bit value (hi:lo) modulo p; 2^64 = eps, 2^96 = -1.  Result canonical.
+GLD u64 gl_reduce128(u64 lo, u64 hi) {
+    u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    u64 t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;
+    u64 t1 = (hi_lo << 32) - hi_lo;       // hi_lo * eps
+    u64 r = t0 + t1;
+    if (r < t1) r += GL_EPS;
+    return r >= GL_P ? r - GL_P : r;
+}
+GLD u64 gl_mulhi(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+GLD u64 gl_mul(u64 a, u64 b) { return gl_reduce128(a * b, gl_mulhi(a, b)); }
+GLD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+// a*b + c (c canonical): one reduction
+GLD u64 gl_mul_add(u64 a, u64 b, u64 c) {
+    u64 lo = a * b, hi = gl_mulhi(a, b);
+    u64 l2 = lo + c;
+    hi += (l2 < lo);
+    return gl_reduce128(l2, hi);
+}
+GLD u64 gl_pow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) { if (e & 1) r = gl_mul(r, b); b = gl_mul(b, b); e >>= 1; }
+    return r;
+}
+GLD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+GLD u64 gl_root(u32 k) { return gl_pow(GL_POW2_GEN, 1ULL << (32 - k)); }  // primitive_root_of_unity(k)
+
+struct gl2 { u64 a, b; };
+GLD gl2 gl2_make(u64 a, u64 b) { gl2 r; r.a = a; r.b = b; return r; }
+GLD gl2 gl2_add(gl2 x, gl2 y) { return gl2_make(gl_add(x.a, y.a), gl_add(x.b, y.b)); }
+GLD gl2 gl2_sub(gl2 x, gl2 y) { return gl2_make(gl_sub(x.a, y.a), gl_sub(x.b, y.b)); }
+GLD gl2 gl2_mul(gl2 x, gl2 y) {
+    u64 bb = gl_mul(x.b, y.b);
+    u64 w = gl_add(gl_add(gl_dbl(gl_dbl(bb)), gl_dbl(bb)), bb);   // 7*bb
+    return gl2_make(gl_add(gl_mul(x.a, y.a), w), gl_add(gl_mul(x.a, y.b), gl_mul(x.b, y.a)));
+}
+GLD gl2 gl2_scale(gl2 x, u64 s) { return gl2_make(gl_mul(x.a, s), gl_mul(x.b, s)); }
+GLD gl2 gl2_inv(gl2 x) {
+    u64 bb = gl_mul(x.b, x.b);
+    u64 w = gl_add(gl_add(gl_dbl(gl_dbl(bb)), gl_dbl(bb)), bb);
+    u64 d = gl_inv(gl_sub(gl_mul(x.a, x.a), w));
+    return gl2_make(gl_mul(x.a, d), gl_mul(gl_neg(x.b), d));
+}
+GLD gl2 gl2_pow(gl2 b, u64 e) {
+    gl2 r = gl2_make(1, 0);
+    while (e) { if (e & 1) r = gl2_mul(r, b); b = gl2_mul(b, b); e >>= 1; }
+    return r;
+}
+
+GLD u32 bitrev_u32(u32 x, u32 bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    u32 r = 0;
+    for (u32 i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+#endif
+}

@@ -1,0 +1,227 @@
+// PoseidonGoldilocks hashing kernels: leaf sponges over column-major LDE values, Merkle interior levels, caps.
+// Mirrors plonky2 0.2.2 hash::{hashing::hash_n_to_m_no_pad, hashing::hash_or_noop, poseidon::PoseidonHash::two_to_one,
+// merkle_tree::MerkleTree::new} (crate pinned at /root/reference/Cargo.lock:3441-3443), reached from
+// the reference at /root/reference/ops/src/lib.rs:52 through PolynomialBatch::from_values.
+//
+// Layout: one thread = one leaf.  Leaves are rows of a column-major matrix, so lane i reads element i of each
+// column: every global load is a fully coalesced 512-byte wave access.  The 12-word sponge state stays in VGPRs.
+#include "zk_internal.h"
+#include "poseidon.cuh"
+
+// leaf i = (cols[c*stride + i])_{c < n_cols};  digest -> out[4*i .. 4*i+3]
+__global__ __launch_bounds__(256) void hash_leaves_colmajor_kernel(const u64 *__restrict__ cols, size_t stride, u32 n_cols,
+                                                                   size_t n_leaves, u64 *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    if (n_cols <= 4) {            // hash_or_noop: short leaves are copied, zero padded
+        for (u32 c = 0; c < n_cols; c++) s[c] = cols[(size_t)c * stride + i];
+    } else {
+        const u64 *p = cols + i;
+        u32 c = 0;
+        for (; c + 8 <= n_cols; c += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = p[(size_t)(c + k) * stride];
+            psd::permute(s);
+        }
+        if (c < n_cols) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (c + k < n_cols) s[k] = p[(size_t)(c + k) * stride];
+            psd::permute(s);
+        }
+    }
+    ulonglong2 *o = (ulonglong2 *)(out + 4 * i);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// leaf i = rows[i*leaf_len .. (i+1)*leaf_len)
+__global__ __launch_bounds__(256) void hash_leaves_rowmajor_kernel(const u64 *__restrict__ rows, u32 leaf_len, size_t n_leaves,
+                                                                   u64 *__restrict__ out, int canon) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    const u64 *p = rows + i * (size_t)leaf_len;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    if (leaf_len <= 4) {
+        for (u32 c = 0; c < leaf_len; c++) s[c] = canon ? gl_canon(p[c]) : p[c];
+    } else {
+        for (u32 c = 0; c < leaf_len; c += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (c + k < leaf_len) s[k] = canon ? gl_canon(p[c + k]) : p[c + k];
+            psd::permute(s);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * i + k] = s[k];
+}
+
+// parent j = two_to_one(child 2j, child 2j+1) = permute(L | R | 0^4)[0..4]
+__global__ __launch_bounds__(256) void merkle_level_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parents) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_parents) return;
+    const ulonglong2 *c = (const ulonglong2 *)(child + 8 * j);
+    ulonglong2 a = c[0], b = c[1], d = c[2], e = c[3];
+    u64 s[12] = {a.x, a.y, b.x, b.y, d.x, d.y, e.x, e.y, 0, 0, 0, 0};
+    psd::permute(s);
+    ulonglong2 *o = (ulonglong2 *)(parent + 4 * j);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+__global__ __launch_bounds__(256) void permute_batch_kernel(u64 *states, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = gl_canon(states[12 * i + k]);
+    psd::permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
+}
+
+__global__ __launch_bounds__(256) void two_to_one_batch_kernel(const u64 *l, const u64 *r, size_t n, u64 *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { s[k] = gl_canon(l[4 * i + k]); s[4 + k] = gl_canon(r[4 * i + k]); s[8 + k] = 0; }
+    psd::permute(s);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * i + k] = s[k];
+}
+
+// upstream's recursive digest layout: position of node j at `depth` below a cap node over m leaves
+__device__ __forceinline__ size_t layout_off(size_t m, u32 depth, size_t j) {
+    size_t off = 0;
+    while (depth > 1) {
+        size_t half_nodes = (size_t)1 << (depth - 1);
+        if (j >= half_nodes) { off += m; j -= half_nodes; }
+        m >>= 1; depth--;
+    }
+    return off + (m - 2) + j;
+}
+// levels (level-order) -> digests (upstream layout)
+__global__ void digests_layout_kernel(const u64 *levels, size_t n_leaves, u32 n_levels, u64 *digests) {
+    // thread = one digest of levels 0 .. n_levels-2
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = 2 * (n_leaves - (n_leaves >> (n_levels - 1)));
+    if (g >= total) return;
+    u32 k = 0; size_t off = 0, cnt = n_leaves;
+    while (g >= off + cnt) { off += cnt; cnt >>= 1; k++; }
+    size_t i = g - off;
+    u32 depth = n_levels - 1 - k;
+    size_t ncap = n_leaves >> (n_levels - 1), m = n_leaves / ncap, sub_len = 2 * m - 2;
+    size_t per_sub = (size_t)1 << depth;
+    size_t sub = i / per_sub, j = i % per_sub;
+    size_t dst = sub * sub_len + layout_off(m, depth, j);
+#pragma unroll
+    for (int w = 0; w < 4; w++) digests[4 * dst + w] = levels[4 * g + w];
+}
+
+static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uint32_t n_cols, size_t n_leaves, u64 *digests) {
+    ZK_LAUNCH(ctx, "poseidon_leaf_hash", hash_leaves_colmajor_kernel, grid1(n_leaves), dim3(256), 0, cols, stride, n_cols, n_leaves, digests);
+    return ZK_OK;
+}
+int32_t zk_hash_leaves_rowmajor(zk_ctx *ctx, const u64 *rows, uint32_t leaf_len, size_t n_leaves, u64 *digests) {
+    ZK_LAUNCH(ctx, "poseidon_leaf_hash_rows", hash_leaves_rowmajor_kernel, grid1(n_leaves), dim3(256), 0, rows, leaf_len, n_leaves, digests, 1);
+    return ZK_OK;
+}
+int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap_height) {
+    size_t cnt = n_leaves;
+    u64 *cur = levels;
+    while (cnt > ((size_t)1 << cap_height)) {
+        u64 *nxt = cur + 4 * cnt;
+        ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_kernel, grid1(cnt / 2), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
+        cur = nxt; cnt >>= 1;
+    }
+    return ZK_OK;
+}
+int32_t zk_digests_upstream_layout(zk_ctx *ctx, const u64 *levels, size_t n_leaves, uint32_t n_levels, u64 *d_digests) {
+    size_t total = 2 * (n_leaves - (n_leaves >> (n_levels - 1)));
+    if (total) ZK_LAUNCH(ctx, "digests_layout", digests_layout_kernel, grid1(total), dim3(256), 0, levels, n_leaves, n_levels, d_digests);
+    return ZK_OK;
+}
+
+static uint32_t ilog2_exact(size_t x) { uint32_t l = 0; while (((size_t)1 << l) < x) l++; return ((size_t)1 << l) == x ? l : 0xFFFFFFFFu; }
+
+extern "C" {
+
+int32_t zk_poseidon_permute_batch(zk_ctx *ctx, uint64_t *states, size_t n) {
+    if (!ctx || (!states && n)) return ZK_ERR_INVALID_ARG;
+    if (!n) return ZK_OK;
+    hipSetDevice(ctx->device);
+    size_t bytes = n * 12 * sizeof(u64);
+    u64 *d = (u64 *)ctx->alloc(bytes);
+    if (!d) return ZK_ERR_OOM;
+    int32_t rc = zk_dev_upload(ctx, d, states, bytes);
+    if (rc == ZK_OK) {
+        ZK_LAUNCH(ctx, "poseidon_permute_batch", permute_batch_kernel, grid1(n), dim3(256), 0, d, n);
+        rc = zk_dev_download(ctx, states, d, bytes);
+    }
+    ctx->release(d);
+    return rc;
+}
+
+int32_t zk_hash_no_pad_batch(zk_ctx *ctx, const uint64_t *rows, size_t n_rows, uint32_t row_len, uint64_t *out) {
+    if (!ctx || !rows || !out || row_len == 0) return ZK_ERR_INVALID_ARG;
+    if (!n_rows) return ZK_OK;
+    hipSetDevice(ctx->device);
+    size_t bytes = n_rows * row_len * sizeof(u64);
+    u64 *d = (u64 *)ctx->alloc(bytes), *o = (u64 *)ctx->alloc(n_rows * 4 * sizeof(u64));
+    int32_t rc = (d && o) ? zk_dev_upload(ctx, d, rows, bytes) : ZK_ERR_OOM;
+    if (rc == ZK_OK) rc = zk_hash_leaves_rowmajor(ctx, d, row_len, n_rows, o);
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, out, o, n_rows * 4 * sizeof(u64));
+    ctx->release(d); ctx->release(o);
+    return rc;
+}
+
+int32_t zk_two_to_one_batch(zk_ctx *ctx, const uint64_t *left, const uint64_t *right, size_t n, uint64_t *out) {
+    if (!ctx || !left || !right || !out) return ZK_ERR_INVALID_ARG;
+    if (!n) return ZK_OK;
+    hipSetDevice(ctx->device);
+    size_t bytes = n * 4 * sizeof(u64);
+    u64 *l = (u64 *)ctx->alloc(bytes), *r = (u64 *)ctx->alloc(bytes), *o = (u64 *)ctx->alloc(bytes);
+    int32_t rc = (l && r && o) ? ZK_OK : ZK_ERR_OOM;
+    if (rc == ZK_OK) rc = zk_dev_upload(ctx, l, left, bytes);
+    if (rc == ZK_OK) rc = zk_dev_upload(ctx, r, right, bytes);
+    if (rc == ZK_OK) {
+        ZK_LAUNCH(ctx, "poseidon_two_to_one", two_to_one_batch_kernel, grid1(n), dim3(256), 0, (const u64 *)l, (const u64 *)r, n, o);
+        rc = zk_dev_download(ctx, out, o, bytes);
+    }
+    ctx->release(l); ctx->release(r); ctx->release(o);
+    return rc;
+}
+
+int32_t zk_merkle_build(zk_ctx *ctx, const uint64_t *leaves, size_t n_leaves, uint32_t leaf_len, uint32_t cap_height,
+                        uint64_t *cap_out, uint64_t *digests_out) {
+    if (!ctx || !leaves || !cap_out || leaf_len == 0) return ZK_ERR_INVALID_ARG;
+    uint32_t lg = ilog2_exact(n_leaves);
+    if (lg == 0xFFFFFFFFu || cap_height > lg) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    uint32_t n_levels = lg - cap_height + 1;
+    size_t n_dig = zk_level_offset(n_leaves, n_levels);
+    size_t lbytes = n_leaves * leaf_len * sizeof(u64);
+    u64 *d_leaves = (u64 *)ctx->alloc(lbytes), *levels = (u64 *)ctx->alloc(n_dig * 4 * sizeof(u64));
+    int32_t rc = (d_leaves && levels) ? zk_dev_upload(ctx, d_leaves, leaves, lbytes) : ZK_ERR_OOM;
+    if (rc == ZK_OK) rc = zk_hash_leaves_rowmajor(ctx, d_leaves, leaf_len, n_leaves, levels);
+    if (rc == ZK_OK) rc = zk_merkle_levels(ctx, levels, n_leaves, cap_height);
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, cap_out, levels + 4 * zk_level_offset(n_leaves, n_levels - 1), ((size_t)4 << cap_height) * sizeof(u64));
+    if (rc == ZK_OK && digests_out && n_levels > 1) {
+        size_t total = 2 * (n_leaves - ((size_t)1 << cap_height));
+        u64 *dd = (u64 *)ctx->alloc(total * 4 * sizeof(u64));
+        if (!dd) rc = ZK_ERR_OOM;
+        if (rc == ZK_OK) rc = zk_digests_upstream_layout(ctx, levels, n_leaves, n_levels, dd);
+        if (rc == ZK_OK) rc = zk_dev_download(ctx, digests_out, dd, total * 4 * sizeof(u64));
+        ctx->release(dd);
+    }
+    ctx->release(d_leaves); ctx->release(levels);
+    return rc;
+}
+
+}  // extern "C"

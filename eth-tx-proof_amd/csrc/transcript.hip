@@ -1,0 +1,175 @@
+// Device-resident Fiat-Shamir transcript.
+// Mirrors plonky2 0.2.2 iop::challenger::Challenger<F, PoseidonHash> (crate pinned at
+// /root/reference/Cargo.lock:3441-3443; semantics: SURVEY.md A6): overwrite-mode duplex sponge, rate 8, challenges
+// popped from the back of the output buffer.
+// The sponge state lives in HBM and is advanced by a tiny kernel on the ctx stream, so caps, openings and challenges
+// never cross PCIe while a proof is being produced; every consumer kernel reads its challenges from device memory.
+#include "zk_internal.h"
+#include "poseidon.cuh"
+#include "transcript.h"
+
+__device__ void ch_duplex(DevChallenger *c) {
+    u64 s[12];
+    for (int i = 0; i < 12; i++) s[i] = c->state[i];
+    for (u32 i = 0; i < c->n_in; i++) s[i] = c->inbuf[i];
+    c->n_in = 0;
+    psd::permute(s);
+    for (int i = 0; i < 12; i++) c->state[i] = s[i];
+    for (int i = 0; i < 8; i++) c->outbuf[i] = s[i];
+    c->n_out = 8;
+}
+__device__ void ch_observe(DevChallenger *c, u64 x) {
+    c->n_out = 0;
+    c->inbuf[c->n_in++] = gl_canon(x);
+    if (c->n_in == 8) ch_duplex(c);
+}
+__device__ u64 ch_get(DevChallenger *c) {
+    if (c->n_in || !c->n_out) ch_duplex(c);
+    return c->outbuf[--c->n_out];
+}
+
+__global__ void transcript_kernel(DevChallenger *c, TOpList ops, u64 *err) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < ops.n; k++) {
+        const TOp &o = ops.op[k];
+        switch (o.kind) {
+        case TOP_INIT:
+            for (int i = 0; i < 12; i++) c->state[i] = 0;
+            c->n_in = 0; c->n_out = 0;
+            break;
+        case TOP_OBSERVE:
+            for (u32 i = 0; i < o.n; i++) ch_observe(c, o.src[i]);
+            break;
+        case TOP_OBSERVE_BASE_AS_EXT:
+            for (u32 i = 0; i < o.n; i++) { ch_observe(c, o.src[i]); ch_observe(c, 0); }
+            break;
+        case TOP_GET:
+            for (u32 i = 0; i < o.n; i++) o.dst[i] = ch_get(c);
+            break;
+        case TOP_COMPACT:
+            if (c->n_in) ch_duplex(c);
+            c->n_out = 0;
+            if (o.dst) for (int i = 0; i < 12; i++) o.dst[i] = c->state[i];
+            break;
+        case TOP_POW_SETUP: {
+            // fri_proof_of_work: duplex_intermediate_state = sponge state with pending inputs written in; dst[12] = witness position
+            for (int i = 0; i < 12; i++) o.dst[i] = c->state[i];
+            for (u32 i = 0; i < c->n_in; i++) o.dst[i] = c->inbuf[i];
+            o.dst[12] = c->n_in;
+            o.dst[13] = ~0ULL;            // best witness so far
+            break;
+        }
+        case TOP_POW_FINISH: {
+            u64 w = o.src[13];
+            if (w == ~0ULL) { atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW); w = 0; }
+            ch_observe(c, w);
+            u64 resp = ch_get(c);
+            if ((u32)__clzll((long long)resp) < o.n) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW);
+            o.dst[0] = w;
+            break;
+        }
+        case TOP_GET_INDICES:
+            // fri_prover_query_rounds: x_index = challenge.to_canonical_u64() as usize % lde_size (lde_size = 2^o.aux)
+            for (u32 i = 0; i < o.n; i++) o.dst[i] = ch_get(c) & (((u64)1 << o.aux) - 1);
+            break;
+        }
+    }
+}
+
+// PoW search: candidate w at state[pos], response = permute(state)[7]; keep the smallest accepted w.
+__global__ __launch_bounds__(256) void pow_grind_kernel(u64 *pow_state /* 14 words */, u64 base, u32 min_zeros) {
+    u64 cand = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pow_state[13] < cand) return;       // a smaller witness is already known
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = pow_state[i];
+    u32 pos = (u32)pow_state[12];
+#pragma unroll
+    for (int i = 0; i < 8; i++) if ((u32)i == pos) s[i] = cand;
+    psd::permute(s);
+    if ((u32)__clzll((long long)s[7]) >= min_zeros) atomicMin((unsigned long long *)&pow_state[13], (unsigned long long)cand);
+}
+
+int32_t zk_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops) {
+    ZK_LAUNCH(ctx, "transcript", transcript_kernel, dim3(1), dim3(64), 0, c, ops, ctx->d_err);
+    return ZK_OK;
+}
+
+int32_t zk_pow_grind(zk_ctx *ctx, DevChallenger *c, u32 min_zeros, u64 *d_pow_state, u64 *d_witness_out) {
+    TOpList a = {}; a.n = 1; a.op[0].kind = TOP_POW_SETUP; a.op[0].dst = d_pow_state;
+    zk_transcript_run(ctx, c, a);
+    // expected 2^min_zeros candidates; 2^(min_zeros+6) of them fail with probability e^-64.  Later blocks exit early
+    // once a smaller witness is recorded.
+    u64 total = (u64)1 << (min_zeros + 6 > 40 ? 40 : min_zeros + 6);
+    u64 per_launch = (u64)1 << 22;
+    for (u64 base = 0; base < total; base += per_launch) {
+        u64 cnt = total - base < per_launch ? total - base : per_launch;
+        ZK_LAUNCH(ctx, "pow_grind", pow_grind_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, d_pow_state, base, min_zeros);
+    }
+    TOpList b = {}; b.n = 1; b.op[0].kind = TOP_POW_FINISH; b.op[0].src = d_pow_state; b.op[0].dst = d_witness_out; b.op[0].n = min_zeros;
+    zk_transcript_run(ctx, c, b);
+    return ZK_OK;
+}
+
+struct zk_challenger { zk_ctx *ctx; DevChallenger *d; u64 *scratch; size_t scratch_words; };
+
+extern "C" {
+
+int32_t zk_challenger_new(zk_ctx *ctx, zk_challenger **out) {
+    if (!ctx || !out) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    zk_challenger *h = new zk_challenger();
+    h->ctx = ctx;
+    h->d = (DevChallenger *)ctx->alloc(sizeof(DevChallenger));
+    h->scratch_words = 4096;
+    h->scratch = (u64 *)ctx->alloc(h->scratch_words * sizeof(u64));
+    if (!h->d || !h->scratch) { delete h; return ZK_ERR_OOM; }
+    TOpList a = {}; a.n = 1; a.op[0].kind = TOP_INIT;
+    zk_transcript_run(ctx, h->d, a);
+    *out = h;
+    return ZK_OK;
+}
+int32_t zk_challenger_free(zk_challenger *h) {
+    if (!h) return ZK_ERR_INVALID_ARG;
+    h->ctx->release(h->d); h->ctx->release(h->scratch);
+    delete h;
+    return ZK_OK;
+}
+int32_t zk_challenger_observe(zk_challenger *h, const uint64_t *elems, uint32_t n) {
+    if (!h || (!elems && n)) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(h->ctx->device);
+    while (n) {
+        uint32_t m = n < h->scratch_words ? n : (uint32_t)h->scratch_words;
+        int32_t rc = zk_dev_upload(h->ctx, h->scratch, elems, m * sizeof(u64));
+        if (rc) return rc;
+        TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = h->scratch; a.op[0].n = m;
+        zk_transcript_run(h->ctx, h->d, a);
+        rc = zk_ctx_synchronize(h->ctx);
+        if (rc) return rc;
+        elems += m; n -= m;
+    }
+    return ZK_OK;
+}
+int32_t zk_challenger_get(zk_challenger *h, uint32_t n, uint64_t *out) {
+    if (!h || (!out && n)) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(h->ctx->device);
+    while (n) {
+        uint32_t m = n < h->scratch_words ? n : (uint32_t)h->scratch_words;
+        TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = h->scratch; a.op[0].n = m;
+        zk_transcript_run(h->ctx, h->d, a);
+        int32_t rc = zk_dev_download(h->ctx, out, h->scratch, m * sizeof(u64));
+        if (rc) return rc;
+        out += m; n -= m;
+    }
+    return ZK_OK;
+}
+int32_t zk_challenger_compact(zk_challenger *h, uint64_t out_state[12]) {
+    if (!h) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(h->ctx->device);
+    TOpList a = {}; a.n = 1; a.op[0].kind = TOP_COMPACT; a.op[0].dst = h->scratch;
+    zk_transcript_run(h->ctx, h->d, a);
+    if (out_state) return zk_dev_download(h->ctx, out_state, h->scratch, 12 * sizeof(u64));
+    return zk_ctx_synchronize(h->ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// Internal host-side declarations shared by the .hip translation units of libzkgl_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/zkgl.h"
+#include "gl64.cuh"
+
+struct ProfRec {
+    std::string name;
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct TwoLevel { u64 *A = nullptr, *B = nullptr; };   // x -> A[x & 2047] * B[x >> 11]
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    // caching device allocator (stream-ordered reuse on the ctx stream)
+    std::multimap<size_t, void *> free_blocks;
+    std::unordered_map<void *, size_t> block_size;
+    size_t bytes_allocated = 0;
+    // per-kernel hipEvent profiler
+    bool prof = false;
+    std::vector<ProfRec> prof_recs;
+    std::unordered_map<std::string, int> prof_index;
+    std::vector<hipEvent_t> event_pool;
+    // twiddle / scale tables (device)
+    std::map<std::pair<int, int>, u64 *> digit_tw;                 // (W, inverse)
+    std::map<std::pair<int, int>, TwoLevel> root_tab;              // (m, inverse): w_{2^m}^{+-x}
+    std::map<std::tuple<u64, u64, int>, TwoLevel> scale_tab;       // (base, premul, log_count): premul*base^j
+    std::map<std::pair<int, int>, u64 *> lagrange_tab;             // (log_n, rate_bits): L_first|L_last on the coset, R order
+    u64 *d_err = nullptr;                                          // device error word (first error wins)
+
+    void *alloc(size_t bytes);
+    void release(void *p);
+    int32_t fail(int32_t code, const std::string &msg) { last_error = msg; return code; }
+    void prof_flush();
+};
+
+struct ProfScope {
+    zk_ctx *ctx; int idx; hipEvent_t e0, e1;
+    ProfScope(zk_ctx *c, const char *name);
+    ~ProfScope();
+};
+
+#define ZK_LAUNCH(ctx, name, kern, grid, block, shmem, ...)                                   \
+    do {                                                                                      \
+        ProfScope _ps((ctx), (name));                                                         \
+        hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__);             \
+    } while (0)
+
+#define HIP_TRY(ctx, expr)                                                                    \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return (ctx)->fail(ZK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- tables (ntt.hip)
+u64 *zk_digit_twiddles(zk_ctx *ctx, int W, int inverse);
+TwoLevel zk_root_table(zk_ctx *ctx, int m, int inverse);
+TwoLevel zk_scale_table(zk_ctx *ctx, u64 base, u64 premul, int log_count);
+
+// ---- NTT engines (ntt.hip); all device pointers, column-major with explicit column strides (in elements)
+// natural order in -> bit-reversed order out.  pre (optional): multiply input j by pre.A/B(j).  post_const: multiply outputs.
+int32_t zk_ntt_dif(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_t out_stride, int k, int n_cols,
+                   int inverse, const TwoLevel *pre, u64 post_const, int canon_in);
+// bit-reversed order in -> natural order out (permute_out=0) or bit-reversed out (permute_out=1; needs tmp of n_cols*2^k
+// when k needs more than one pass).  pre (optional) is indexed by the coefficient index j = bitrev(pos); post by output index.
+int32_t zk_ntt_dit(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_t out_stride, int k, int n_cols,
+                   int inverse, const TwoLevel *pre, const TwoLevel *post, int permute_out, u64 *tmp, size_t tmp_stride);
+int32_t zk_bitrev_copy(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_t out_stride, int k, int n_cols);
+
+// ---- Poseidon / Merkle (poseidon_kernels.hip)
+// digests of n_leaves leaves held column-major: leaf i = (cols[c*stride + i])_c
+int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uint32_t n_cols, size_t n_leaves, u64 *digests);
+// digests of n_leaves leaves held row-major (leaf_len contiguous elements each)
+int32_t zk_hash_leaves_rowmajor(zk_ctx *ctx, const u64 *rows, uint32_t leaf_len, size_t n_leaves, u64 *digests);
+// levels: level 0 = n_leaves digests at `levels`, level k follows; builds up to the cap level
+int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap_height);
+// levels (level order) -> upstream's recursive `digests` layout, device to device
+int32_t zk_digests_upstream_layout(zk_ctx *ctx, const u64 *levels, size_t n_leaves, uint32_t n_levels, u64 *d_digests);
+// evaluate n_cols bit-reversed-coefficient polynomials (2^k coeffs each) at the extension point stored at d_point[0..1]
+// (device memory); writes n_cols ext values to d_out.  scratch is managed internally.
+int32_t zk_eval_cols_at(zk_ctx *ctx, const u64 *coeffs, size_t stride, int k, int n_cols, const u64 *d_point, u64 *d_out);
+static inline size_t zk_level_offset(size_t n_leaves, uint32_t k) {   // in digests
+    size_t off = 0;
+    for (uint32_t j = 0; j < k; j++) off += n_leaves >> j;
+    return off;
+}
+
+struct zk_batch {
+    zk_ctx *ctx;
+    uint32_t log_n, n_cols, rate_bits, cap_height;
+    u64 *coeffs;    // n_cols x n, column-major, BIT-REVERSED coefficient order: coeffs[c*n + bitrev(j)] = c_j
+    u64 *lde;       // n_cols x (n<<rate_bits), column-major, bit-reversed row order (= leaf order)
+    u64 *levels;    // Merkle levels 0..(log L - cap_height), 4 words per digest
+    size_t n() const { return (size_t)1 << log_n; }
+    size_t L() const { return (size_t)1 << (log_n + rate_bits); }
+    uint32_t n_levels() const { return log_n + rate_bits - cap_height + 1; }
+    const u64 *cap() const { return levels + 4 * zk_level_offset(L(), n_levels() - 1); }
+};
+// values_natural == 1: cols are evaluations on the subgroup (from_values); 0: natural-order coefficients (from_coeffs)
+int32_t zk_batch_commit_dev(zk_ctx *ctx, const u64 *d_cols, uint32_t log_n, uint32_t n_cols, uint32_t rate_bits,
+                            uint32_t cap_height, int values_natural, zk_batch **out);

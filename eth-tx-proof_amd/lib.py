@@ -1,0 +1,287 @@
+"""ctypes binding of the product library `csrc/libzkgl_hip.so` (C ABI: include/zkgl.h).
+
+No CPU fallback: a missing library raises at import of a symbol, a missing GPU raises ZkError(ZK_ERR_NO_DEVICE)
+from Context().  Host arrays are numpy uint64; device pointers are plain ints (e.g. torch_tensor.data_ptr()).
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+from ._abi import ERRORS, StarkConfig
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "libzkgl_hip.so")
+_HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "zkgl.h")
+_lib = None
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code, what="", detail=""):
+        self.code = code
+        super().__init__("%s failed: %s (%d) %s" % (what, ERRORS.get(code, "?"), code, detail))
+
+
+def build(force=False, jobs=8):
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _CSRC, "-j%d" % jobs, "libzkgl_hip.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def declared_symbols():
+    """Every function name declared in include/zkgl.h."""
+    txt = open(_HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise FileNotFoundError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(there is no CPU fallback)" % _SO)
+        L = C.CDLL(_SO)
+        L.zk_last_error.restype = C.c_char_p
+        L.zk_ctx_stream.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Context:
+    """zk_ctx: one device + one HIP stream (one per worker thread, like a paladin worker)."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        rc = lib().zk_ctx_create(C.c_int32(device), C.c_void_p(stream), C.byref(self.h))
+        if rc:
+            self.h = None
+            raise ZkError(rc, "zk_ctx_create")
+
+    def _chk(self, rc, what):
+        if rc:
+            raise ZkError(rc, what, lib().zk_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            lib().zk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._chk(lib().zk_ctx_synchronize(self.h), "zk_ctx_synchronize")
+
+    @property
+    def stream(self):
+        return lib().zk_ctx_stream(self.h)
+
+    # ---- profiling
+    def profile(self, on=True):
+        self._chk(lib().zk_profile_enable(self.h, C.c_int32(1 if on else 0)), "zk_profile_enable")
+
+    def profile_reset(self):
+        self._chk(lib().zk_profile_reset(self.h), "zk_profile_reset")
+
+    def profile_report(self):
+        n = lib().zk_profile_count(self.h)
+        out = {}
+        for i in range(n):
+            name, launches, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            lib().zk_profile_get(self.h, C.c_int32(i), C.byref(name), C.byref(launches), C.byref(ms))
+            out[name.value.decode()] = (launches.value, ms.value)
+        return out
+
+    # ---- device memory
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(lib().zk_dev_alloc(self.h, C.c_size_t(nbytes), C.byref(p)), "zk_dev_alloc")
+        return p.value
+
+    def dev_free(self, p):
+        lib().zk_dev_free(self.h, C.c_void_p(p))
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(lib().zk_dev_upload(self.h, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes)), "zk_dev_upload")
+
+    def download(self, dptr, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        self._chk(lib().zk_dev_download(self.h, _p(out), C.c_void_p(dptr), C.c_size_t(out.nbytes)), "zk_dev_download")
+        return out
+
+    # ---- field / NTT  (fft_with_options / ifft_with_options / coset_fft / coset_ifft)
+    def ntt(self, cols, inverse=False, shift=0):
+        a = _u64(cols).copy()
+        a2 = a.reshape(-1, a.shape[-1])
+        log_n = a2.shape[1].bit_length() - 1
+        assert 1 << log_n == a2.shape[1]
+        self._chk(lib().zk_ntt_batch(self.h, _p(a2), C.c_uint32(log_n), C.c_uint32(a2.shape[0]),
+                                     C.c_int32(1 if inverse else 0), C.c_uint64(shift)), "zk_ntt_batch")
+        return a
+
+    def ntt_dev(self, dptr, log_n, n_cols, inverse=False, shift=0):
+        self._chk(lib().zk_ntt_batch_dev(self.h, C.c_void_p(dptr), C.c_uint32(log_n), C.c_uint32(n_cols),
+                                         C.c_int32(1 if inverse else 0), C.c_uint64(shift)), "zk_ntt_batch_dev")
+
+    # ---- Poseidon
+    def poseidon(self, states):
+        s = _u64(states).copy()
+        self._chk(lib().zk_poseidon_permute_batch(self.h, _p(s), C.c_size_t(s.size // 12)), "zk_poseidon_permute_batch")
+        return s
+
+    def hash_rows(self, rows):
+        rows = _u64(rows)
+        out = np.empty((rows.shape[0], 4), dtype=np.uint64)
+        self._chk(lib().zk_hash_no_pad_batch(self.h, _p(rows), C.c_size_t(rows.shape[0]), C.c_uint32(rows.shape[1]), _p(out)),
+                  "zk_hash_no_pad_batch")
+        return out
+
+    def two_to_one(self, left, right):
+        left, right = _u64(left), _u64(right)
+        out = np.empty_like(left)
+        self._chk(lib().zk_two_to_one_batch(self.h, _p(left), _p(right), C.c_size_t(left.size // 4), _p(out)), "zk_two_to_one_batch")
+        return out
+
+    def merkle_build(self, leaves, cap_height, want_digests=True):
+        leaves = _u64(leaves)
+        L, ll = leaves.shape
+        cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        nd = 2 * (L - (1 << cap_height))
+        dig = np.empty((max(nd, 1), 4), dtype=np.uint64)
+        self._chk(lib().zk_merkle_build(self.h, _p(leaves), C.c_size_t(L), C.c_uint32(ll), C.c_uint32(cap_height), _p(cap),
+                                        _p(dig) if want_digests else None), "zk_merkle_build")
+        return cap, dig[:nd]
+
+    # ---- PolynomialBatch
+    def batch_from_values(self, cols, rate_bits=1, cap_height=4):
+        return Batch(self, cols, rate_bits, cap_height, coeffs=False)
+
+    def batch_from_coeffs(self, cols, rate_bits=1, cap_height=4):
+        return Batch(self, cols, rate_bits, cap_height, coeffs=True)
+
+    def batch_from_values_dev(self, dptr, log_n, n_cols, rate_bits=1, cap_height=4):
+        return Batch(self, None, rate_bits, cap_height, coeffs=False, dev=(dptr, log_n, n_cols))
+
+    def challenger(self):
+        return Challenger(self)
+
+
+class Batch:
+    """zk_batch: PolynomialBatch::{from_values, from_coeffs}; device resident."""
+
+    def __init__(self, ctx, cols, rate_bits, cap_height, coeffs, dev=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.rate_bits, self.cap_height = rate_bits, cap_height
+        cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        if dev is None:
+            cols = _u64(cols)
+            self.n_cols, n = cols.shape
+            self.log_n = n.bit_length() - 1
+            assert 1 << self.log_n == n
+            f = lib().zk_batch_from_coeffs if coeffs else lib().zk_batch_from_values
+            rc = f(ctx.h, _p(cols), C.c_uint32(self.log_n), C.c_uint32(self.n_cols), C.c_uint32(rate_bits),
+                   C.c_uint32(cap_height), C.byref(self.h), _p(cap))
+        else:
+            dptr, self.log_n, self.n_cols = dev
+            f = lib().zk_batch_from_coeffs_dev if coeffs else lib().zk_batch_from_values_dev
+            rc = f(ctx.h, C.c_void_p(dptr), C.c_uint32(self.log_n), C.c_uint32(self.n_cols), C.c_uint32(rate_bits),
+                   C.c_uint32(cap_height), C.byref(self.h), _p(cap))
+        if rc:
+            self.h = None
+            ctx._chk(rc, "zk_batch_from_*")
+        self.cap = cap
+        self.L = 1 << (self.log_n + rate_bits)
+
+    def free(self):
+        if self.h:
+            lib().zk_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+    def lde_rows(self, idx, step=1):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        out = np.empty((idx.size, self.n_cols), dtype=np.uint64)
+        self.ctx._chk(lib().zk_batch_get_lde_rows(self.h, _p(idx), C.c_uint32(idx.size), C.c_uint32(step), _p(out)), "zk_batch_get_lde_rows")
+        return out
+
+    def leaf(self, leaf_idx):
+        out = np.empty(self.n_cols, dtype=np.uint64)
+        self.ctx._chk(lib().zk_batch_get_leaf(self.h, C.c_uint32(leaf_idx), _p(out)), "zk_batch_get_leaf")
+        return out
+
+    def prove(self, leaf_idx):
+        ns = self.log_n + self.rate_bits - self.cap_height
+        out = np.empty((max(ns, 1), 4), dtype=np.uint64)
+        self.ctx._chk(lib().zk_batch_merkle_prove(self.h, C.c_uint32(leaf_idx), _p(out)), "zk_batch_merkle_prove")
+        return out[:ns]
+
+    def digests(self):
+        nd = 2 * (self.L - (1 << self.cap_height))
+        out = np.empty((max(nd, 1), 4), dtype=np.uint64)
+        self.ctx._chk(lib().zk_batch_get_digests(self.h, _p(out)), "zk_batch_get_digests")
+        return out[:nd]
+
+    def coeffs(self, col):
+        out = np.empty(1 << self.log_n, dtype=np.uint64)
+        self.ctx._chk(lib().zk_batch_get_coeffs(self.h, C.c_uint32(col), _p(out)), "zk_batch_get_coeffs")
+        return out
+
+    def eval_at(self, point):
+        pt = _u64(point)
+        out = np.empty((self.n_cols, 2), dtype=np.uint64)
+        self.ctx._chk(lib().zk_batch_eval_at(self.h, _p(pt), _p(out)), "zk_batch_eval_at")
+        return out
+
+
+class Challenger:
+    """zk_challenger: Challenger<F, PoseidonHash>, state resident in HBM."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx._chk(lib().zk_challenger_new(ctx.h, C.byref(self.h)), "zk_challenger_new")
+
+    def observe(self, xs):
+        xs = _u64(np.atleast_1d(xs)).ravel()
+        self.ctx._chk(lib().zk_challenger_observe(self.h, _p(xs), C.c_uint32(xs.size)), "zk_challenger_observe")
+
+    def get(self, n=1):
+        out = np.empty(n, dtype=np.uint64)
+        self.ctx._chk(lib().zk_challenger_get(self.h, C.c_uint32(n), _p(out)), "zk_challenger_get")
+        return out
+
+    def compact(self):
+        out = np.empty(12, dtype=np.uint64)
+        self.ctx._chk(lib().zk_challenger_compact(self.h, _p(out)), "zk_challenger_compact")
+        return out
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                lib().zk_challenger_free(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+P = 0xFFFFFFFF00000001
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+def field_rand(rng, shape):
+    """uniform canonical field elements"""
+    a = rng.integers(0, 1 << 64, size=shape, dtype=np.uint64)
+    while True:
+        bad = a >= np.uint64(P)
+        if not bad.any():
+            return a
+        a[bad] = rng.integers(0, 1 << 64, size=int(bad.sum()), dtype=np.uint64)
+
+
+EDGE = np.array([0, 1, P - 1, (1 << 32) - 1, 1 << 32, 1 << 63, P, (1 << 64) - 1], dtype=np.uint64)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import orc as _orc
+    _orc.lib()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def zk():
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import lib as zl
+    return zl
+
+
+@pytest.fixture(scope="session")
+def ctx(zk):
+    c = zk.Context(0)          # raises without a GPU: there is no CPU fallback
+    yield c
+    c.close()

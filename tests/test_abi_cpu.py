@@ -1,0 +1,38 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/zkgl.h declares; no compute without a GPU."""
+import ctypes as C
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(zk):
+    L = zk.lib()
+    names = zk.declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback(zk):
+    """Without a HIP device the product refuses to create a context (ZK_ERR_NO_DEVICE) -- it never computes on the host."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(zk.ZkError) as e:
+        zk.Context(0)
+    assert e.value.code == -7
+
+
+def test_null_arguments_are_rejected(zk):
+    L = zk.lib()
+    assert L.zk_ctx_create(C.c_int32(0), None, None) == -1
+    assert L.zk_ctx_destroy(None) == -1
+    assert L.zk_batch_free(None) == -1
+    assert L.zk_ntt_batch(None, None, C.c_uint32(3), C.c_uint32(1), C.c_int32(0), C.c_uint64(0)) == -1
+
+
+def test_standard_fast_config(zk):
+    from eth_tx_proof_amd._abi import StarkConfig, standard_fast_config
+    c = StarkConfig()
+    zk.lib().zk_stark_config_standard_fast(C.byref(c))
+    ref = standard_fast_config()
+    assert [getattr(c, f) for f, _ in c._fields_] == [getattr(ref, f) for f, _ in ref._fields_] == [100, 2, 1, 4, 16, 4, 5, 84]

