@@ -1,0 +1,36 @@
+// Internal interfaces between the prover translation units (prover_*.hip).
+#pragma once
+#include "zk_internal.h"
+#include "transcript.h"
+
+// device copy of an AIR (program, constants, helper descriptors live in HBM)
+struct DevAir {
+    const zk_air *host;
+    zk_instr *d_instrs;
+    u64 *d_constants;
+    zk_helper_desc *d_helpers;
+    u32 n_aux(u32 nch) const { return host->n_helpers ? nch * (host->n_helpers + 1) : 0; }
+};
+
+// prover_aux.hip
+int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc *d_helpers, u32 nch, const u64 *d_chal,
+                           const u64 *d_trace, u32 log_n, u64 *d_aux);
+
+// prover_quotient.hip: compute_quotient_polys -> d_qcoeffs: (nch << rate_bits) columns of n coefficients, natural order
+int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &cfg, const zk_batch *trace, const zk_batch *aux,
+                        const u64 *d_public, const u64 *d_chal, const u64 *d_alphas, u64 *d_qcoeffs);
+
+// prover_fri.hip: PolynomialBatch::prove_openings + fri_proof, everything written into the device proof buffer
+struct FriLayout {           // offsets (in words) into the proof buffer, per table
+    size_t o_local, o_next, o_aux, o_auxn, o_zs, o_q;     // openings
+    size_t o_nl, o_layer_caps, o_flen, o_final, o_witness, o_queries;
+    size_t per_query;
+};
+int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *trace, const zk_batch *aux,
+                         const zk_batch *quot, const u64 *d_zeta /* zeta, g*zeta */, u64 *d_proof, const FriLayout &lay);
+
+static inline void zk_fri_arities(const zk_stark_config &cfg, u32 degree_bits, u32 *out, u32 *n_out) {
+    u32 d = degree_bits, k = 0;
+    while (d > cfg.fri_final_poly_bits && d + cfg.rate_bits - cfg.fri_arity_bits >= cfg.cap_height) { out[k++] = cfg.fri_arity_bits; d -= cfg.fri_arity_bits; }
+    *n_out = k;
+}

@@ -1,0 +1,172 @@
+// Auxiliary (logUp / cross-table-lookup shaped) columns and the synthetic witness generator.
+// Mirrors starky 0.4.0 lookup::lookup_helper_columns and cross_table_lookup::partial_sums (crate pinned at
+// /root/reference/Cargo.lock:4529-4531): helper columns are sums of reciprocals
+// of challenge-combined trace columns (batch inversion), Z columns are running sums.  Here
+//   h_m[row] = 1/(t[a0] + beta t[b0] + gamma) + 1/(t[a1] + beta t[b1] + gamma),   Z[row] = sum_{s >= row} sum_m h_m[s].
+// One thread = one row; reciprocals are batched 8 helper columns at a time (Montgomery's trick, one Fermat inversion).
+#include "zk_internal.h"
+#include "prover.h"
+
+// a^(p-2) with p-2 = 2^64 - 2^32 - 1 = 0xFFFFFFFEFFFFFFFF
+__device__ __forceinline__ u64 gl_inv_dev(u64 a) {
+    // exponent bits (msb first): 31 ones, a zero, 32 ones
+    u64 t = a;                       // a^(2^1 - 1)
+    u64 x2 = gl_mul(gl_sqr(t), a);   // 2 ones
+    u64 x4 = gl_mul(gl_sqr(gl_sqr(x2)), x2);
+    u64 x8 = x4; for (int i = 0; i < 4; i++) x8 = gl_sqr(x8); x8 = gl_mul(x8, x4);
+    u64 x16 = x8; for (int i = 0; i < 8; i++) x16 = gl_sqr(x16); x16 = gl_mul(x16, x8);
+    u64 x24 = x16; for (int i = 0; i < 8; i++) x24 = gl_sqr(x24); x24 = gl_mul(x24, x8);
+    u64 x28 = x24; for (int i = 0; i < 4; i++) x28 = gl_sqr(x28); x28 = gl_mul(x28, x4);
+    u64 x30 = gl_mul(gl_sqr(gl_sqr(x28)), x2);
+    u64 x31 = gl_mul(gl_sqr(x30), a);
+    u64 x32 = gl_mul(gl_sqr(x31), a);
+    u64 r = gl_sqr(x31);             // 31 ones followed by a zero
+    for (int i = 0; i < 32; i++) r = gl_sqr(r);
+    return gl_mul(r, x32);
+}
+
+#define AUX_CHUNK 8
+__global__ __launch_bounds__(256) void aux_helpers_kernel(const u64 *__restrict__ trace, size_t n, const zk_helper_desc *__restrict__ helpers,
+                                                          u32 H, u32 nch, const u64 *__restrict__ chal, u64 *__restrict__ aux,
+                                                          u64 *__restrict__ rowsum, u64 *err) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 j = blockIdx.y;
+    if (r >= n) return;
+    u64 beta = chal[2 * j], gamma = chal[2 * j + 1];
+    u64 total = 0;
+    for (u32 m0 = 0; m0 < H; m0 += AUX_CHUNK) {
+        u64 num[AUX_CHUNK], den[AUX_CHUNK], pre[AUX_CHUNK];
+        u64 acc = 1;
+#pragma unroll
+        for (int k = 0; k < AUX_CHUNK; k++) {
+            if (m0 + k < H) {
+                zk_helper_desc d = helpers[m0 + k];
+                u64 x1 = gl_add(gl_mul_add(beta, trace[(size_t)d.b0 * n + r], trace[(size_t)d.a0 * n + r]), gamma);
+                u64 x2 = gl_add(gl_mul_add(beta, trace[(size_t)d.b1 * n + r], trace[(size_t)d.a1 * n + r]), gamma);
+                num[k] = gl_add(x1, x2); den[k] = gl_mul(x1, x2);
+            } else { num[k] = 0; den[k] = 1; }
+            pre[k] = acc;
+            acc = gl_mul(acc, den[k]);
+        }
+        if (acc == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_ZERO_INVERSE);
+        u64 inv = gl_inv_dev(acc);
+#pragma unroll
+        for (int k = AUX_CHUNK - 1; k >= 0; k--) {
+            u64 dinv = gl_mul(inv, pre[k]);
+            inv = gl_mul(inv, den[k]);
+            if (m0 + k < H) {
+                u64 h = gl_mul(num[k], dinv);
+                aux[(size_t)(j * H + m0 + k) * n + r] = h;
+                total = gl_add(total, h);
+            }
+        }
+    }
+    rowsum[(size_t)j * n + r] = total;
+}
+
+// ---- suffix sums over rows: Z[r] = sum_{s >= r} rowsum[s]   (three phases, 2048 rows per workgroup)
+#define SCAN_BLOCK 2048
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const u64 *rowsum, size_t n, u64 *blocksum) {
+    __shared__ u64 red[256];
+    u32 j = blockIdx.y; size_t b = blockIdx.x;
+    u64 acc = 0;
+    for (u32 i = threadIdx.x; i < SCAN_BLOCK; i += 256) { size_t r = b * SCAN_BLOCK + i; if (r < n) acc = gl_add(acc, rowsum[(size_t)j * n + r]); }
+    red[threadIdx.x] = acc; __syncthreads();
+    for (u32 s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = gl_add(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) blocksum[(size_t)j * gridDim.x + b] = red[0];
+}
+__global__ void scan_block_suffix_kernel(u64 *blocksum, u32 nb) {   // exclusive suffix: out[b] = sum_{b' > b}
+    if (threadIdx.x != 0) return;
+    u32 j = blockIdx.x;
+    u64 run = 0;
+    for (u32 b = nb; b-- > 0;) { u64 v = blocksum[(size_t)j * nb + b]; blocksum[(size_t)j * nb + b] = run; run = gl_add(run, v); }
+}
+__global__ __launch_bounds__(256) void scan_final_kernel(const u64 *rowsum, size_t n, const u64 *blocksum, u64 *Z /* nch columns of n */) {
+    __shared__ u64 sh[SCAN_BLOCK];
+    __shared__ u64 part[256];
+    u32 j = blockIdx.y; size_t b = blockIdx.x;
+    const u32 per = SCAN_BLOCK / 256;
+    // thread t owns rows [t*per, (t+1)*per) of this block
+    for (u32 i = threadIdx.x; i < SCAN_BLOCK; i += 256) { size_t r = b * SCAN_BLOCK + i; sh[i] = r < n ? rowsum[(size_t)j * n + r] : 0; }
+    __syncthreads();
+    u64 acc = 0;
+    for (u32 i = 0; i < per; i++) acc = gl_add(acc, sh[threadIdx.x * per + i]);
+    part[threadIdx.x] = acc; __syncthreads();
+    if (threadIdx.x == 0) { u64 run = blocksum[(size_t)j * gridDim.x + b]; for (u32 t = 256; t-- > 0;) { u64 v = part[t]; part[t] = run; run = gl_add(run, v); } }
+    __syncthreads();
+    u64 run = part[threadIdx.x];
+    for (u32 i = per; i-- > 0;) { run = gl_add(run, sh[threadIdx.x * per + i]); sh[threadIdx.x * per + i] = run; }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < SCAN_BLOCK; i += 256) { size_t r = b * SCAN_BLOCK + i; if (r < n) Z[(size_t)j * n + r] = sh[i]; }
+}
+
+int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc *d_helpers, u32 nch, const u64 *d_chal,
+                           const u64 *d_trace, u32 log_n, u64 *d_aux) {
+    u32 H = air->n_helpers;
+    if (!H) return ZK_OK;
+    size_t n = (size_t)1 << log_n;
+    u64 *rowsum = (u64 *)ctx->alloc(n * nch * sizeof(u64));
+    u32 nb = (u32)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    u64 *blocksum = (u64 *)ctx->alloc((size_t)nb * nch * sizeof(u64));
+    if (!rowsum || !blocksum) return ZK_ERR_OOM;
+    ZK_LAUNCH(ctx, "aux_helpers", aux_helpers_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, d_trace, n, d_helpers, H, nch, d_chal,
+              d_aux, rowsum, ctx->d_err);
+    ZK_LAUNCH(ctx, "aux_scan_sums", scan_block_sums_kernel, dim3(nb, nch), dim3(256), 0, (const u64 *)rowsum, n, blocksum);
+    ZK_LAUNCH(ctx, "aux_scan_suffix", scan_block_suffix_kernel, dim3(nch), dim3(64), 0, blocksum, nb);
+    ZK_LAUNCH(ctx, "aux_scan_final", scan_final_kernel, dim3(nb, nch), dim3(256), 0, (const u64 *)rowsum, n, (const u64 *)blocksum,
+              d_aux + (size_t)nch * H * n);
+    ctx->release(rowsum); ctx->release(blocksum);
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------ synthetic witness
+__device__ __forceinline__ u64 splitmix_field(u64 st) {
+    for (;;) {
+        st += 0x9E3779B97F4A7C15ULL;
+        u64 z = st;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        if (z < GL_P) return z;
+    }
+}
+// one thread per column triple (rows are a recurrence: inherently serial, like the EVM interpreter upstream)
+__global__ void synth_trace_kernel(u32 n_cols, u32 log_n, u64 seed, u64 *t, u64 *pub) {
+    size_t n = (size_t)1 << log_n;
+    u32 T = n_cols / 3;
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= T + (n_cols - 3 * T)) return;
+    if (k < T) {
+        u64 *a = t + (size_t)(3 * k) * n, *b = a + n, *c = b + n;
+        u64 va = splitmix_field(seed + 3 * k), vb = splitmix_field(seed + 3 * k + 1), vc = splitmix_field(seed + 3 * k + 2);
+        for (size_t r = 0; r < n; r++) {
+            a[r] = va; b[r] = vb; c[r] = vc;
+            u64 ab = gl_mul(va, vb);
+            u64 na = gl_add(ab, vc), nb = gl_add(gl_mul(vb, vb), va), nc = gl_add(gl_mul(ab, vc), 1);
+            va = na; vb = nb; vc = nc;
+        }
+    } else {
+        u32 col = 3 * T + (k - T);
+        u64 *a = t + (size_t)col * n;
+        u64 v = splitmix_field(seed + col);
+        for (size_t r = 0; r < n; r++) { a[r] = v; v = gl_add(v, 1); }
+    }
+}
+__global__ void synth_pub_kernel(u32 n_cols, u32 log_n, const u64 *t, u64 *pub) {
+    size_t n = (size_t)1 << log_n;
+    pub[0] = t[0]; pub[1] = n_cols > 1 ? t[n] : 0; pub[2] = t[n - 1];
+}
+
+extern "C" int32_t zk_synth_trace_dev(zk_ctx *ctx, uint32_t n_cols, uint32_t log_n, uint64_t seed, uint64_t *d_trace, uint64_t *public_inputs_out) {
+    if (!ctx || !d_trace || n_cols == 0 || log_n > 28) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    u32 work = n_cols / 3 + (n_cols % 3);
+    u64 *d_pub = (u64 *)ctx->alloc(3 * sizeof(u64));
+    if (!d_pub) return ZK_ERR_OOM;
+    ZK_LAUNCH(ctx, "synth_trace", synth_trace_kernel, dim3((work + 63) / 64), dim3(64), 0, n_cols, log_n, seed, (u64 *)d_trace, d_pub);
+    ZK_LAUNCH(ctx, "synth_pub", synth_pub_kernel, dim3(1), dim3(1), 0, n_cols, log_n, (const u64 *)d_trace, d_pub);
+    int32_t rc = ZK_OK;
+    if (public_inputs_out) rc = zk_dev_download(ctx, public_inputs_out, d_pub, 3 * sizeof(u64));
+    ctx->release(d_pub);
+    return rc;
+}

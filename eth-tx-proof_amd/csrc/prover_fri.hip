@@ -1,0 +1,349 @@
+// FRI opening proof on the device: batch combination, commit phase (fold + Merkle per layer), proof of work, queries.
+// Mirrors plonky2 0.2.2 fri::oracle::PolynomialBatch::prove_openings and fri::prover::{fri_proof, fri_committed_trees,
+// fri_proof_of_work, fri_prover_query_rounds} (crate pinned at /root/reference/Cargo.lock:3441-3443; SURVEY.md A8,
+// 8a row a13).  Reached from the reference at /root/reference/ops/src/lib.rs:52.
+//
+// Same field values as upstream, different route (all exact arithmetic, so the bits agree):
+//   * sum_j alpha^j f_j is formed on the bit-reversed coefficient arrays (one coalesced pass over every column);
+//   * (P - P(z))/(X - z) is taken pointwise on the LDE coset -- P(z) is the alpha-reduction of the openings -- instead
+//     of a serial synthetic division; the result IS layer 0 of the commit phase, already in leaf order;
+//   * folding is done on natural-order coefficients (contiguous groups of 16), each next layer is one DIF NTT.
+// Extension vectors are stored as two base columns (re | im) so the NTT kernels treat them as a 2-column batch.
+#include "zk_internal.h"
+#include "prover.h"
+#include "poseidon.cuh"
+
+__device__ inline gl2 gl2_pow_u32(gl2 b, u32 e) {
+    gl2 r = gl2_make(1, 0);
+    while (e) { if (e & 1) r = gl2_mul(r, b); b = gl2_mul(b, b); e >>= 1; }
+    return r;
+}
+__device__ __forceinline__ u64 gl_inv_fermat(u64 a) {
+    u64 x2 = gl_mul(gl_sqr(a), a);
+    u64 x4 = gl_mul(gl_sqr(gl_sqr(x2)), x2);
+    u64 x8 = x4; for (int i = 0; i < 4; i++) x8 = gl_sqr(x8); x8 = gl_mul(x8, x4);
+    u64 x16 = x8; for (int i = 0; i < 8; i++) x16 = gl_sqr(x16); x16 = gl_mul(x16, x8);
+    u64 x24 = x16; for (int i = 0; i < 8; i++) x24 = gl_sqr(x24); x24 = gl_mul(x24, x8);
+    u64 x28 = x24; for (int i = 0; i < 4; i++) x28 = gl_sqr(x28); x28 = gl_mul(x28, x4);
+    u64 x30 = gl_mul(gl_sqr(gl_sqr(x28)), x2);
+    u64 x31 = gl_mul(gl_sqr(x30), a);
+    u64 x32 = gl_mul(gl_sqr(x31), a);
+    u64 r = gl_sqr(x31);
+    for (int i = 0; i < 32; i++) r = gl_sqr(r);
+    return gl_mul(r, x32);
+}
+
+// alpha^j for j < cnt, plus the two ReducingFactor shifts alpha^(C+A), alpha^nch at the end
+__global__ void alpha_pows_kernel(const u64 *alpha, u32 cnt, u32 sh1, u32 sh2, u64 *out) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cnt + 2) return;
+    gl2 a = gl2_make(alpha[0], alpha[1]);
+    u32 e = j < cnt ? j : (j == cnt ? sh1 : sh2);
+    gl2 r = gl2_pow_u32(a, e);
+    out[2 * j] = r.a; out[2 * j + 1] = r.b;
+}
+
+struct CombineParams {
+    const u64 *seg[3]; u32 cnt[3];     // trace, aux, quotient coefficient matrices (column stride n)
+    u32 nch;                           // the last nch aux columns are the Z columns (batch at the point 1)
+    size_t n;
+    const u64 *apow;                   // alpha^j (ext)
+    u64 *P;                            // 6 columns of n: P0.re P0.im P1.re P1.im P2.re P2.im
+};
+// ReducingFactor::reduce_polys_base for all three batches in one pass over the coefficient columns
+__global__ __launch_bounds__(256) void fri_combine_kernel(CombineParams p) {
+    size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= p.n) return;
+    u64 ra = 0, rb = 0;
+    u32 j = 0;
+    u64 p1a = 0, p1b = 0;
+    for (int sgi = 0; sgi < 3; sgi++) {
+        if (sgi == 2) { p1a = ra; p1b = rb; }          // batch g*zeta = trace | aux prefix
+        const u64 *base = p.seg[sgi] + pos;
+        for (u32 c = 0; c < p.cnt[sgi]; c++, j++) {
+            u64 v = base[(size_t)c * p.n];
+            ra = gl_add(ra, gl_mul(v, p.apow[2 * j]));
+            rb = gl_add(rb, gl_mul(v, p.apow[2 * j + 1]));
+        }
+    }
+    p.P[pos] = ra; p.P[p.n + pos] = rb;
+    p.P[2 * p.n + pos] = p1a; p.P[3 * p.n + pos] = p1b;
+    if (p.nch && p.cnt[1]) {
+        u64 za = 0, zb = 0;
+        const u64 *zc = p.seg[1] + (size_t)(p.cnt[1] - p.nch) * p.n + pos;
+        for (u32 k = 0; k < p.nch; k++) {
+            u64 v = zc[(size_t)k * p.n];
+            za = gl_add(za, gl_mul(v, p.apow[2 * k])); zb = gl_add(zb, gl_mul(v, p.apow[2 * k + 1]));
+        }
+        p.P[4 * p.n + pos] = za; p.P[5 * p.n + pos] = zb;
+    }
+}
+
+// PrecomputedReducedOpenings: y_b = sum_j alpha^j opening_j per batch, read from the proof buffer
+__global__ void reduce_openings_kernel(const u64 *proof, FriLayout lay, u32 C, u32 A, u32 Q, u32 nch, const u64 *apow, u64 *y) {
+    __shared__ u64 red[2 * 256];
+    u32 b = blockIdx.x, t = threadIdx.x;
+    gl2 acc = gl2_make(0, 0);
+    u32 cnt = b == 0 ? C + A + Q : b == 1 ? C + A : nch;
+    for (u32 j = t; j < cnt; j += 256) {
+        gl2 v;
+        if (b == 0) {
+            const u64 *src = j < C ? proof + lay.o_local + 2 * j : j < C + A ? proof + lay.o_aux + 2 * (j - C) : proof + lay.o_q + 2 * (j - C - A);
+            v = gl2_make(src[0], src[1]);
+        } else if (b == 1) {
+            const u64 *src = j < C ? proof + lay.o_next + 2 * j : proof + lay.o_auxn + 2 * (j - C);
+            v = gl2_make(src[0], src[1]);
+        } else v = gl2_make(proof[lay.o_zs + j], 0);
+        acc = gl2_add(acc, gl2_mul(v, gl2_make(apow[2 * j], apow[2 * j + 1])));
+    }
+    red[2 * t] = acc.a; red[2 * t + 1] = acc.b; __syncthreads();
+    for (u32 s = 128; s > 0; s >>= 1) {
+        if (t < s) { red[2 * t] = gl_add(red[2 * t], red[2 * (t + s)]); red[2 * t + 1] = gl_add(red[2 * t + 1], red[2 * (t + s) + 1]); }
+        __syncthreads();
+    }
+    if (t == 0) { y[2 * b] = red[0]; y[2 * b + 1] = red[1]; }
+}
+
+struct QuotParams {
+    const u64 *Pval;          // 2*nb columns of L (leaf order)
+    size_t L; u32 lgL, nb;
+    const u64 *xA, *xB;       // x_i = g w_L^i
+    const u64 *pts;           // zeta (2), g_n*zeta (2)
+    const u64 *y;             // reduced openings (2 per batch)
+    const u64 *shifts;        // alpha^(C+A) (2), alpha^nch (2)
+    u64 *F;                   // F.re | F.im, leaf order
+};
+// final values  F(x) = ((q0 * a^cnt1 + q1) * a^cnt2 + q2)(x),  q_b(x) = (P_b(x) - y_b) / (x - z_b)
+__global__ __launch_bounds__(256) void fri_quotient_kernel(QuotParams p) {
+    size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= p.L) return;
+    u32 i = bitrev_u32((u32)s, p.lgL);
+    u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);
+    gl2 den[3], num[3];
+    u64 nrm[3], pre[3];
+    u64 acc = 1;
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        if (b < (int)p.nb) {
+            gl2 z = b == 0 ? gl2_make(p.pts[0], p.pts[1]) : b == 1 ? gl2_make(p.pts[2], p.pts[3]) : gl2_make(1, 0);
+            den[b] = gl2_make(gl_sub(x, z.a), gl_neg(z.b));
+            u64 bb = gl_mul(den[b].b, den[b].b);
+            u64 w7 = gl_add(gl_add(gl_dbl(gl_dbl(bb)), gl_dbl(bb)), bb);
+            nrm[b] = gl_sub(gl_mul(den[b].a, den[b].a), w7);            // norm = a^2 - 7 b^2
+            num[b] = gl2_make(gl_sub(p.Pval[(size_t)(2 * b) * p.L + s], p.y[2 * b]), gl_sub(p.Pval[(size_t)(2 * b + 1) * p.L + s], p.y[2 * b + 1]));
+        } else { nrm[b] = 1; den[b] = gl2_make(1, 0); num[b] = gl2_make(0, 0); }
+        pre[b] = acc; acc = gl_mul(acc, nrm[b]);
+    }
+    u64 inv = gl_inv_fermat(acc);
+    gl2 F = gl2_make(0, 0);
+    gl2 q[3];
+#pragma unroll
+    for (int b = 2; b >= 0; b--) {
+        u64 ninv = gl_mul(inv, pre[b]);
+        inv = gl_mul(inv, nrm[b]);
+        gl2 dinv = gl2_make(gl_mul(den[b].a, ninv), gl_mul(gl_neg(den[b].b), ninv));   // conj / norm
+        q[b] = gl2_mul(num[b], dinv);
+    }
+    F = q[0];
+    F = gl2_add(gl2_mul(F, gl2_make(p.shifts[0], p.shifts[1])), q[1]);
+    if (p.nb == 3) F = gl2_add(gl2_mul(F, gl2_make(p.shifts[2], p.shifts[3])), q[2]);
+    p.F[s] = F.a; p.F[p.L + s] = F.b;
+}
+
+// leaves of a commit-phase layer: `arity` consecutive extension values, flattened [a0,b0,a1,b1,...]
+__global__ __launch_bounds__(256) void fri_leaf_hash_kernel(const u64 *__restrict__ re, const u64 *__restrict__ im, size_t n_leaves, u32 arity,
+                                                            u64 *__restrict__ out) {
+    size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    const u64 *r = re + l * arity, *m = im + l * arity;
+    for (u32 c = 0; c < arity; c += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s[2 * k] = r[c + k]; s[2 * k + 1] = m[c + k]; }
+        psd::permute(s);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * l + k] = s[k];
+}
+
+// coeffs'[i] = reduce_with_powers(coeffs[arity*i .. arity*(i+1)], beta)   (natural order, re|im columns)
+__global__ __launch_bounds__(256) void fri_fold_kernel(const u64 *__restrict__ re, const u64 *__restrict__ im, size_t n_out, u32 arity,
+                                                       const u64 *beta, u64 *__restrict__ ore, u64 *__restrict__ oim) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    gl2 b = gl2_make(beta[0], beta[1]);
+    gl2 acc = gl2_make(0, 0);
+    for (u32 t = arity; t-- > 0;) acc = gl2_add(gl2_mul(acc, b), gl2_make(re[i * arity + t], im[i * arity + t]));
+    ore[i] = acc.a; oim[i] = acc.b;
+}
+
+__global__ void interleave_kernel(const u64 *re, const u64 *im, u32 n, u64 *out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[2 * i] = re[i]; out[2 * i + 1] = im[i]; }
+}
+__global__ void copy_words_kernel(const u64 *src, u64 *dst, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+struct QueryParams {
+    u32 n_oracles, n_layers, cap_height, lgL;
+    const u64 *lde[3]; const u64 *levels[3]; u32 n_cols[3];
+    const u64 *lre[8], *lim[8], *llevels[8]; u32 arity_bits[8];
+    const u64 *idx;
+    u64 *out; size_t per_query;
+};
+// fri_prover_query_rounds: one workgroup per query round gathers leaves and Merkle paths into the proof buffer
+__global__ __launch_bounds__(256) void fri_query_kernel(QueryParams p) {
+    const u32 q = blockIdx.x, t = threadIdx.x;
+    u64 *dst = p.out + (size_t)q * p.per_query;
+    size_t x = (size_t)p.idx[q];
+    const size_t L = (size_t)1 << p.lgL;
+    const u32 npath = p.lgL - p.cap_height;
+    for (u32 o = 0; o < p.n_oracles; o++) {
+        for (u32 c = t; c < p.n_cols[o]; c += 256) dst[c] = p.lde[o][(size_t)c * L + x];
+        dst += p.n_cols[o];
+        for (u32 w = t; w < npath * 4; w += 256) {
+            u32 k = w >> 2;
+            size_t off = 0;
+            for (u32 j = 0; j < k; j++) off += L >> j;
+            dst[w] = p.levels[o][4 * (off + ((x >> k) ^ 1)) + (w & 3)];
+        }
+        dst += (size_t)npath * 4;
+    }
+    u32 lg = p.lgL;
+    for (u32 l = 0; l < p.n_layers; l++) {
+        u32 ab = p.arity_bits[l], arity = 1u << ab;
+        size_t leaf = x >> ab;
+        for (u32 w = t; w < 2 * arity; w += 256) dst[w] = (w & 1) ? p.lim[l][leaf * arity + (w >> 1)] : p.lre[l][leaf * arity + (w >> 1)];
+        dst += 2 * arity;
+        u32 depth = lg - ab, ns = depth - p.cap_height;
+        size_t nl = (size_t)1 << depth;
+        for (u32 w = t; w < ns * 4; w += 256) {
+            u32 k = w >> 2;
+            size_t off = 0;
+            for (u32 j = 0; j < k; j++) off += nl >> j;
+            dst[w] = p.llevels[l][4 * (off + ((leaf >> k) ^ 1)) + (w & 3)];
+        }
+        dst += (size_t)ns * 4;
+        x = leaf; lg = depth;
+    }
+}
+
+__global__ void write_word_kernel(u64 *dst, u64 v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
+
+static inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *trace, const zk_batch *aux,
+                         const zk_batch *quot, const u64 *d_zeta, u64 *d_proof, const FriLayout &lay) {
+    const u32 log_n = trace->log_n, rate_bits = cfg.rate_bits, lgL = log_n + rate_bits, nch = cfg.num_challenges;
+    const size_t n = (size_t)1 << log_n, L = n << rate_bits;
+    const u32 C = trace->n_cols, A = aux ? aux->n_cols : 0, Q = quot->n_cols;
+    const u32 nb = A ? 3 : 2, capw = 4u << cfg.cap_height;
+    u32 ar[64], nl; zk_fri_arities(cfg, log_n, ar, &nl);
+    if (nl > 8) return ctx->fail(ZK_ERR_INVALID_ARG, "fri: more than 8 reduction layers");
+    int32_t rc = ZK_OK;
+
+    // ---- alpha, alpha powers, reduced openings
+    u64 *d_alpha = (u64 *)ctx->alloc(2 * sizeof(u64));
+    u32 cnt = C + A + Q;
+    u64 *d_apow = (u64 *)ctx->alloc((size_t)(cnt + 2) * 2 * sizeof(u64));
+    u64 *d_y = (u64 *)ctx->alloc(6 * sizeof(u64));
+    u64 *P = (u64 *)ctx->alloc(6 * n * sizeof(u64)), *Pval = (u64 *)ctx->alloc(6 * L * sizeof(u64)), *tmp = (u64 *)ctx->alloc(6 * n * sizeof(u64));
+    u64 *F = (u64 *)ctx->alloc(2 * L * sizeof(u64)), *Fco = (u64 *)ctx->alloc(2 * L * sizeof(u64));
+    if (!d_alpha || !d_apow || !d_y || !P || !Pval || !tmp || !F || !Fco) return ZK_ERR_OOM;
+    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_alpha; a.op[0].n = 2; zk_transcript_run(ctx, ch, a); }
+    ZK_LAUNCH(ctx, "fri_alpha_pows", alpha_pows_kernel, g1(cnt + 2), dim3(256), 0, (const u64 *)d_alpha, cnt, C + A, nch, d_apow);
+    ZK_LAUNCH(ctx, "fri_reduce_openings", reduce_openings_kernel, dim3(nb), dim3(256), 0, (const u64 *)d_proof, lay, C, A, Q, nch, (const u64 *)d_apow, d_y);
+
+    // ---- sum_j alpha^j f_j on the coefficient arrays, then onto the LDE coset
+    CombineParams cp = {};
+    cp.seg[0] = trace->coeffs; cp.cnt[0] = C; cp.seg[1] = aux ? aux->coeffs : nullptr; cp.cnt[1] = A; cp.seg[2] = quot->coeffs; cp.cnt[2] = Q;
+    cp.nch = nch; cp.n = n; cp.apow = d_apow; cp.P = P;
+    ZK_LAUNCH(ctx, "fri_combine", fri_combine_kernel, g1(n), dim3(256), 0, cp);
+    for (u32 par = 0; rc == ZK_OK && par < (1u << rate_bits); par++) {
+        u64 shift = gl_mul(GL_GEN, gl_pow(gl_root(lgL), par));
+        TwoLevel pre = zk_scale_table(ctx, shift, 1, log_n);
+        rc = zk_ntt_dit(ctx, P, n, Pval + (size_t)bitrev_u32(par, rate_bits) * n, L, log_n, 2 * nb, 0, &pre, nullptr, 1, tmp, n);
+    }
+    if (rc) return rc;
+    QuotParams qp = {};
+    qp.Pval = Pval; qp.L = L; qp.lgL = lgL; qp.nb = nb;
+    TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
+    qp.xA = xs.A; qp.xB = xs.B; qp.pts = d_zeta; qp.y = d_y; qp.shifts = d_apow + 2 * cnt; qp.F = F;
+    ZK_LAUNCH(ctx, "fri_quotient", fri_quotient_kernel, g1(L), dim3(256), 0, qp);
+
+    // ---- lde_final_poly coefficients (natural order): coset_ifft(g) of the final values
+    {
+        TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);
+        rc = zk_ntt_dit(ctx, F, L, Fco, L, lgL, 2, 1, nullptr, &post, 0, nullptr, 0);
+        if (rc) return rc;
+    }
+
+    // ---- fri_committed_trees
+    ZK_LAUNCH(ctx, "write_word", write_word_kernel, dim3(1), dim3(1), 0, d_proof + lay.o_nl, (u64)nl);
+    const u64 *vre[9], *vim[9]; u64 *lvl[8]; u64 *owned[40]; int n_owned = 0;
+    vre[0] = F; vim[0] = F + L;
+    u64 *cre = Fco, *cim = Fco + L;          // current coefficients (natural order)
+    size_t cur = L; u32 cur_lg = lgL;
+    u64 shift = GL_GEN;
+    u64 *d_beta = (u64 *)ctx->alloc(2 * 8 * sizeof(u64));
+    if (!d_beta) return ZK_ERR_OOM;
+    for (u32 l = 0; l < nl; l++) {
+        u32 arity = 1u << ar[l];
+        size_t n_leaves = cur >> ar[l];
+        u32 depth = cur_lg - ar[l];
+        size_t n_dig = zk_level_offset(n_leaves, depth - cfg.cap_height + 1);
+        lvl[l] = (u64 *)ctx->alloc(n_dig * 4 * sizeof(u64));
+        if (!lvl[l]) return ZK_ERR_OOM;
+        owned[n_owned++] = lvl[l];
+        ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_kernel, g1(n_leaves), dim3(256), 0, vre[l], vim[l], n_leaves, arity, lvl[l]);
+        zk_merkle_levels(ctx, lvl[l], n_leaves, cfg.cap_height);
+        const u64 *cap = lvl[l] + 4 * zk_level_offset(n_leaves, depth - cfg.cap_height);
+        u64 *pcap = d_proof + lay.o_layer_caps + (size_t)l * capw;
+        ZK_LAUNCH(ctx, "copy_words", copy_words_kernel, g1(capw), dim3(256), 0, cap, pcap, capw);
+        { TOpList a = {}; a.n = 2; a.op[0].kind = TOP_OBSERVE; a.op[0].src = pcap; a.op[0].n = capw;
+          a.op[1].kind = TOP_GET; a.op[1].dst = d_beta + 2 * l; a.op[1].n = 2; zk_transcript_run(ctx, ch, a); }
+        size_t nxt = cur >> ar[l];
+        u64 *nco = (u64 *)ctx->alloc(2 * nxt * sizeof(u64)), *nva = (u64 *)ctx->alloc(2 * nxt * sizeof(u64));
+        if (!nco || !nva) return ZK_ERR_OOM;
+        owned[n_owned++] = nco; owned[n_owned++] = nva;
+        ZK_LAUNCH(ctx, "fri_fold", fri_fold_kernel, g1(nxt), dim3(256), 0, (const u64 *)cre, (const u64 *)cim, nxt, arity, (const u64 *)(d_beta + 2 * l), nco, nco + nxt);
+        cre = nco; cim = nco + nxt;
+        shift = gl_pow(shift, arity);
+        cur = nxt; cur_lg = depth;
+        TwoLevel pre = zk_scale_table(ctx, shift, 1, cur_lg);
+        rc = zk_ntt_dif(ctx, nco, cur, nva, cur, cur_lg, 2, 0, &pre, 0, 0);
+        if (rc) return rc;
+        vre[l + 1] = nva; vim[l + 1] = nva + cur;
+    }
+    // ---- final polynomial: coeffs.truncate(len >> rate_bits); observe
+    u32 flen = (u32)(cur >> rate_bits);
+    ZK_LAUNCH(ctx, "write_word", write_word_kernel, dim3(1), dim3(1), 0, d_proof + lay.o_flen, (u64)flen);
+    ZK_LAUNCH(ctx, "interleave", interleave_kernel, g1(flen), dim3(256), 0, (const u64 *)cre, (const u64 *)cim, flen, d_proof + lay.o_final);
+    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + lay.o_final; a.op[0].n = 2 * flen; zk_transcript_run(ctx, ch, a); }
+
+    // ---- proof of work, query indices
+    u64 *d_pow = (u64 *)ctx->alloc(16 * sizeof(u64)), *d_idx = (u64 *)ctx->alloc((size_t)cfg.num_query_rounds * sizeof(u64));
+    if (!d_pow || !d_idx) return ZK_ERR_OOM;
+    zk_pow_grind(ctx, ch, cfg.proof_of_work_bits, d_pow, d_proof + lay.o_witness);
+    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET_INDICES; a.op[0].dst = d_idx; a.op[0].n = cfg.num_query_rounds; a.op[0].aux = lgL; zk_transcript_run(ctx, ch, a); }
+
+    QueryParams q = {};
+    q.n_layers = nl; q.cap_height = cfg.cap_height; q.lgL = lgL;
+    u32 no = 0;
+    q.lde[no] = trace->lde; q.levels[no] = trace->levels; q.n_cols[no] = C; no++;
+    if (A) { q.lde[no] = aux->lde; q.levels[no] = aux->levels; q.n_cols[no] = A; no++; }
+    q.lde[no] = quot->lde; q.levels[no] = quot->levels; q.n_cols[no] = Q; no++;
+    q.n_oracles = no;
+    for (u32 l = 0; l < nl; l++) { q.lre[l] = vre[l]; q.lim[l] = vim[l]; q.llevels[l] = lvl[l]; q.arity_bits[l] = ar[l]; }
+    q.idx = d_idx; q.out = d_proof + lay.o_queries; q.per_query = lay.per_query;
+    ZK_LAUNCH(ctx, "fri_query_gather", fri_query_kernel, dim3(cfg.num_query_rounds), dim3(256), 0, q);
+
+    for (int i = 0; i < n_owned; i++) ctx->release(owned[i]);
+    ctx->release(d_alpha); ctx->release(d_apow); ctx->release(d_y); ctx->release(P); ctx->release(Pval); ctx->release(tmp);
+    ctx->release(F); ctx->release(Fco); ctx->release(d_beta); ctx->release(d_pow); ctx->release(d_idx);
+    return ZK_OK;
+}

@@ -1,0 +1,242 @@
+// zk_prove_tables: the whole STARK proof of one unit of work, enqueued on one HIP stream with a single host
+// synchronisation at the end.
+// Mirrors evm_arithmetization 0.1.3 prover::prove_with_traces (commit every trace, observe every cap, draw the CTL
+// challenges, then prove the tables one after another on the shared challenger) driving starky 0.4.0
+// prover::prove_with_commitment (crates pinned at /root/reference/Cargo.lock:1675-1677 and :4529-4531; transcript
+// order: SURVEY.md A7).  This is the work behind the reference's single hot call
+//   generate_txn_proof(p_state(), input, None)       /root/reference/ops/src/lib.rs:52
+// up to (not including) the Plonk recursion wrappers.  Witness generation (generate_traces, a CPU EVM
+// interpreter upstream) is out of scope: traces are an input.
+#include "zk_internal.h"
+#include "prover.h"
+#include <memory>
+
+__global__ void zeta_kernel(u64 *zeta /* in: zeta; out: +2 = g_n * zeta */, u32 log_n, u64 g_n, u64 *err) {
+    if (threadIdx.x || blockIdx.x) return;
+    gl2 z = gl2_make(zeta[0], zeta[1]);
+    gl2 p = z;
+    for (u32 i = 0; i < log_n; i++) p = gl2_mul(p, p);
+    if (p.a == 1 && p.b == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_ZETA_IN_SUBGROUP);
+    zeta[2] = gl_mul(z.a, g_n); zeta[3] = gl_mul(z.b, g_n);
+    zeta[4] = 1; zeta[5] = 0;
+}
+__global__ void take_re_kernel(const u64 *ext, u32 n, u64 *out) { u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = ext[2 * i]; }
+__global__ void copy_words2_kernel(const u64 *src, u64 *dst, u32 n) { u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
+
+struct TableLayout { size_t base, o_trace_cap, o_aux_cap, o_quot_cap; FriLayout fri; size_t end; };
+
+static u32 n_aux_cols(const zk_air *air, u32 nch) { return air->n_helpers ? nch * (air->n_helpers + 1) : 0; }
+
+static TableLayout table_layout(const zk_stark_config &cfg, const zk_table &t, size_t base) {
+    TableLayout y = {};
+    const u32 nch = cfg.num_challenges, capw = 4u << cfg.cap_height;
+    const u32 C = t.air->n_trace_cols, A = n_aux_cols(t.air, nch), Q = nch << cfg.rate_bits;
+    const u32 lgL = t.log_n + cfg.rate_bits;
+    size_t o = base;
+    y.base = o; o += 3;
+    y.o_trace_cap = o; o += capw;
+    if (A) { y.o_aux_cap = o; o += capw; }
+    y.o_quot_cap = o; o += capw;
+    y.fri.o_local = o; o += 2 * (size_t)C;
+    y.fri.o_next = o; o += 2 * (size_t)C;
+    y.fri.o_aux = o; o += 2 * (size_t)A;
+    y.fri.o_auxn = o; o += 2 * (size_t)A;
+    y.fri.o_zs = o; if (A) o += nch;
+    y.fri.o_q = o; o += 2 * (size_t)Q;
+    u32 ar[64], nl; zk_fri_arities(cfg, t.log_n, ar, &nl);
+    y.fri.o_nl = o; o += 1;
+    y.fri.o_layer_caps = o; o += (size_t)nl * capw;
+    u32 d = t.log_n; for (u32 l = 0; l < nl; l++) d -= ar[l];
+    y.fri.o_flen = o; o += 1;
+    y.fri.o_final = o; o += 2 * ((size_t)1 << d);
+    y.fri.o_witness = o; o += 1;
+    size_t per_q = (size_t)(C + A + Q) + (size_t)(A ? 3 : 2) * 4 * (lgL - cfg.cap_height);
+    u32 lg = lgL;
+    for (u32 l = 0; l < nl; l++) { lg -= ar[l]; per_q += (2u << ar[l]) + 4 * (size_t)(lg - cfg.cap_height); }
+    y.fri.per_query = per_q;
+    y.fri.o_queries = o; o += per_q * cfg.num_query_rounds;
+    y.end = o;
+    return y;
+}
+
+extern "C" size_t zk_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables) {
+    if (!cfg || !tables) return 0;
+    size_t o = 2;
+    for (u32 t = 0; t < n_tables; t++) o = table_layout(*cfg, tables[t], o).end;
+    return o;
+}
+
+static inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
+                                   uint64_t *proof_out, size_t cap_words, size_t *len_words) {
+    if (!ctx || !cfgp || !tables || nt == 0 || !proof_out) return ZK_ERR_INVALID_ARG;
+    const zk_stark_config &cfg = *cfgp;
+    if (cfg.num_challenges == 0 || cfg.num_challenges > 4 || cfg.rate_bits != 1 || cfg.cap_height > 8 || cfg.fri_arity_bits == 0 || cfg.fri_arity_bits > 6)
+        return ctx->fail(ZK_ERR_INVALID_ARG, "prove: unsupported StarkConfig");
+    for (u32 t = 0; t < nt; t++) {
+        if (!tables[t].air || !tables[t].trace || tables[t].log_n > 26 || tables[t].log_n + cfg.rate_bits < cfg.cap_height)
+            return ctx->fail(ZK_ERR_INVALID_ARG, "prove: bad table");
+    }
+    hipSetDevice(ctx->device);
+    const u32 nch = cfg.num_challenges, capw = 4u << cfg.cap_height;
+    std::vector<TableLayout> lay(nt);
+    size_t total = 2;
+    for (u32 t = 0; t < nt; t++) { lay[t] = table_layout(cfg, tables[t], total); total = lay[t].end; }
+    if (len_words) *len_words = total;
+    if (cap_words < total) return ctx->fail(ZK_ERR_BUFFER_TOO_SMALL, "prove: proof buffer too small");
+
+    int32_t rc = ZK_OK;
+    std::vector<void *> owned;                       // released at the end (stream-ordered)
+    auto A_ = [&](size_t bytes) { void *p = ctx->alloc(bytes); if (p) owned.push_back(p); return p; };
+    u64 *d_proof = (u64 *)A_(total * sizeof(u64));
+    DevChallenger *ch = (DevChallenger *)A_(sizeof(DevChallenger));
+    u64 *d_chal = (u64 *)A_(16 * sizeof(u64)), *d_alphas = (u64 *)A_(8 * sizeof(u64)), *d_zeta = (u64 *)A_(8 * sizeof(u64));
+    if (!d_proof || !ch || !d_chal || !d_alphas || !d_zeta) return ZK_ERR_OOM;
+
+    // host staging that must outlive the async copies: freed after the final synchronisation
+    std::vector<std::unique_ptr<std::vector<u64>>> staging;
+    auto stage = [&](const u64 *src, size_t n) { staging.emplace_back(new std::vector<u64>(src, src + n)); return staging.back()->data(); };
+
+    // header words of the proof (magic, n_tables, per table log_n / C / A)
+    {
+        u64 h2[2] = {0x31465250474C4B5AULL, nt};
+        HIP_TRY(ctx, hipMemcpyAsync(d_proof, stage(h2, 2), 2 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        for (u32 t = 0; t < nt; t++) {
+            u64 h3[3] = {tables[t].log_n, tables[t].air->n_trace_cols, n_aux_cols(tables[t].air, nch)};
+            HIP_TRY(ctx, hipMemcpyAsync(d_proof + lay[t].base, stage(h3, 3), 3 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    // AIRs and public inputs to the device
+    std::vector<DevAir> dair(nt);
+    std::vector<u64 *> d_pub(nt, nullptr);
+    for (u32 t = 0; t < nt; t++) {
+        const zk_air *a = tables[t].air;
+        dair[t].host = a;
+        dair[t].d_instrs = (zk_instr *)A_((size_t)(a->n_instrs ? a->n_instrs : 1) * sizeof(zk_instr));
+        dair[t].d_constants = (u64 *)A_((size_t)(a->n_constants ? a->n_constants : 1) * sizeof(u64));
+        dair[t].d_helpers = (zk_helper_desc *)A_((size_t)(a->n_helpers ? a->n_helpers : 1) * sizeof(zk_helper_desc));
+        d_pub[t] = (u64 *)A_((size_t)(a->n_public_inputs ? a->n_public_inputs : 1) * sizeof(u64));
+        if (!dair[t].d_instrs || !dair[t].d_constants || !dair[t].d_helpers || !d_pub[t]) return ZK_ERR_OOM;
+        if (a->n_instrs) HIP_TRY(ctx, hipMemcpyAsync(dair[t].d_instrs, a->instrs, a->n_instrs * sizeof(zk_instr), hipMemcpyHostToDevice, ctx->stream));
+        if (a->n_constants) {
+            std::vector<u64> c(a->constants, a->constants + a->n_constants);
+            for (auto &v : c) v = gl_canon(v);
+            HIP_TRY(ctx, hipMemcpyAsync(dair[t].d_constants, stage(c.data(), c.size()), c.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (a->n_helpers) HIP_TRY(ctx, hipMemcpyAsync(dair[t].d_helpers, a->helpers, a->n_helpers * sizeof(zk_helper_desc), hipMemcpyHostToDevice, ctx->stream));
+        if (a->n_public_inputs) {
+            std::vector<u64> c(tables[t].public_inputs, tables[t].public_inputs + a->n_public_inputs);
+            for (auto &v : c) v = gl_canon(v);
+            HIP_TRY(ctx, hipMemcpyAsync(d_pub[t], stage(c.data(), c.size()), c.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+
+    std::vector<zk_batch *> trace_b(nt, nullptr), aux_b(nt, nullptr), quot_b(nt, nullptr);
+    std::vector<const u64 *> d_trace(nt, nullptr);
+    auto cleanup = [&]() {
+        for (u32 t = 0; t < nt; t++) { if (trace_b[t]) zk_batch_free(trace_b[t]); if (aux_b[t]) zk_batch_free(aux_b[t]); if (quot_b[t]) zk_batch_free(quot_b[t]); }
+        for (void *p : owned) ctx->release(p);
+    };
+
+    // ---- commit every trace; observe every trace cap, then the public values; draw the lookup/CTL challenges
+    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_INIT; zk_transcript_run(ctx, ch, a); }
+    for (u32 t = 0; t < nt && rc == ZK_OK; t++) {
+        const size_t n = (size_t)1 << tables[t].log_n;
+        const u32 C = tables[t].air->n_trace_cols;
+        if (tables[t].trace_on_device) d_trace[t] = (const u64 *)tables[t].trace;
+        else {
+            u64 *d = (u64 *)A_(n * C * sizeof(u64));
+            if (!d) { rc = ZK_ERR_OOM; break; }
+            if (hipMemcpyAsync(d, tables[t].trace, n * C * sizeof(u64), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = ZK_ERR_HIP; break; }
+            d_trace[t] = d;
+        }
+        rc = zk_batch_commit_dev(ctx, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);
+        if (rc) break;
+        ZK_LAUNCH(ctx, "copy_words", copy_words2_kernel, g1(capw), dim3(256), 0, trace_b[t]->cap(), d_proof + lay[t].o_trace_cap, capw);
+        TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + lay[t].o_trace_cap; a.op[0].n = capw;
+        zk_transcript_run(ctx, ch, a);
+    }
+    if (rc) { hipStreamSynchronize(ctx->stream); cleanup(); return rc; }
+    for (u32 t = 0; t < nt; t++) if (tables[t].air->n_public_inputs) {
+        TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_pub[t]; a.op[0].n = tables[t].air->n_public_inputs;
+        zk_transcript_run(ctx, ch, a);
+    }
+    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_chal; a.op[0].n = 2 * nch; zk_transcript_run(ctx, ch, a); }
+
+    // ---- the tables, one after another on the shared challenger
+    for (u32 t = 0; t < nt && rc == ZK_OK; t++) {
+        const zk_air *air = tables[t].air;
+        const u32 log_n = tables[t].log_n, C = air->n_trace_cols, A = n_aux_cols(air, nch), Q = nch << cfg.rate_bits;
+        const size_t n = (size_t)1 << log_n, L = n << cfg.rate_bits;
+        const TableLayout &y = lay[t];
+        { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_COMPACT; zk_transcript_run(ctx, ch, a); }     // init_challenger_state
+        if (A) {
+            u64 *d_aux = (u64 *)ctx->alloc((size_t)A * n * sizeof(u64));
+            if (!d_aux) { rc = ZK_ERR_OOM; break; }
+            rc = zk_aux_columns_dev(ctx, air, dair[t].d_helpers, nch, d_chal, d_trace[t], log_n, d_aux);
+            if (rc == ZK_OK) rc = zk_batch_commit_dev(ctx, d_aux, log_n, A, cfg.rate_bits, cfg.cap_height, 1, &aux_b[t]);
+            ctx->release(d_aux);
+            if (rc) break;
+            ZK_LAUNCH(ctx, "copy_words", copy_words2_kernel, g1(capw), dim3(256), 0, aux_b[t]->cap(), d_proof + y.o_aux_cap, capw);
+            TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + y.o_aux_cap; a.op[0].n = capw;
+            zk_transcript_run(ctx, ch, a);
+        }
+        { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_alphas; a.op[0].n = nch; zk_transcript_run(ctx, ch, a); }
+        u64 *d_q = (u64 *)ctx->alloc((size_t)nch * L * sizeof(u64));
+        if (!d_q) { rc = ZK_ERR_OOM; break; }
+        rc = zk_quotient_dev(ctx, dair[t], cfg, trace_b[t], aux_b[t], d_pub[t], d_chal, d_alphas, d_q);
+        // the nch*L natural-order coefficients are Q = nch << rate_bits polynomials of n coefficients, back to back
+        if (rc == ZK_OK) rc = zk_batch_commit_dev(ctx, d_q, log_n, Q, cfg.rate_bits, cfg.cap_height, 0, &quot_b[t]);
+        ctx->release(d_q);
+        if (rc) break;
+        ZK_LAUNCH(ctx, "copy_words", copy_words2_kernel, g1(capw), dim3(256), 0, quot_b[t]->cap(), d_proof + y.o_quot_cap, capw);
+        { TOpList a = {}; a.n = 2; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + y.o_quot_cap; a.op[0].n = capw;
+          a.op[1].kind = TOP_GET; a.op[1].dst = d_zeta; a.op[1].n = 2; zk_transcript_run(ctx, ch, a); }
+        ZK_LAUNCH(ctx, "zeta", zeta_kernel, dim3(1), dim3(1), 0, d_zeta, log_n, gl_root(log_n), ctx->d_err);
+
+        // ---- StarkOpeningSet::new: every coefficient polynomial at zeta, trace and aux also at g*zeta, Z columns at 1
+        rc = zk_eval_cols_at(ctx, trace_b[t]->coeffs, n, log_n, C, d_zeta, d_proof + y.fri.o_local);
+        if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, trace_b[t]->coeffs, n, log_n, C, d_zeta + 2, d_proof + y.fri.o_next);
+        if (rc == ZK_OK && A) rc = zk_eval_cols_at(ctx, aux_b[t]->coeffs, n, log_n, A, d_zeta, d_proof + y.fri.o_aux);
+        if (rc == ZK_OK && A) rc = zk_eval_cols_at(ctx, aux_b[t]->coeffs, n, log_n, A, d_zeta + 2, d_proof + y.fri.o_auxn);
+        if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, quot_b[t]->coeffs, n, log_n, Q, d_zeta, d_proof + y.fri.o_q);
+        if (rc == ZK_OK && A) {
+            u64 *zs = (u64 *)ctx->alloc(2 * nch * sizeof(u64));
+            if (!zs) { rc = ZK_ERR_OOM; break; }
+            rc = zk_eval_cols_at(ctx, aux_b[t]->coeffs + (size_t)(A - nch) * n, n, log_n, nch, d_zeta + 4, zs);
+            ZK_LAUNCH(ctx, "take_re", take_re_kernel, dim3(1), dim3(64), 0, (const u64 *)zs, nch, d_proof + y.fri.o_zs);
+            ctx->release(zs);
+        }
+        if (rc) break;
+        // challenger.observe_openings(&openings.to_fri_openings()): zeta batch (local | aux | quotient), g*zeta batch, then Z(1)
+        {
+            TOpList a = {}; int k = 0;
+            a.op[k].kind = TOP_OBSERVE; a.op[k].src = d_proof + y.fri.o_local; a.op[k].n = 2 * C; k++;
+            if (A) { a.op[k].kind = TOP_OBSERVE; a.op[k].src = d_proof + y.fri.o_aux; a.op[k].n = 2 * A; k++; }
+            a.op[k].kind = TOP_OBSERVE; a.op[k].src = d_proof + y.fri.o_q; a.op[k].n = 2 * Q; k++;
+            a.op[k].kind = TOP_OBSERVE; a.op[k].src = d_proof + y.fri.o_next; a.op[k].n = 2 * C; k++;
+            if (A) { a.op[k].kind = TOP_OBSERVE; a.op[k].src = d_proof + y.fri.o_auxn; a.op[k].n = 2 * A; k++; }
+            if (A) { a.op[k].kind = TOP_OBSERVE_BASE_AS_EXT; a.op[k].src = d_proof + y.fri.o_zs; a.op[k].n = nch; k++; }
+            a.n = k;
+            zk_transcript_run(ctx, ch, a);
+        }
+        rc = zk_fri_prove_dev(ctx, cfg, ch, trace_b[t], aux_b[t], quot_b[t], d_zeta, d_proof, y.fri);
+    }
+
+    // ---- the only host synchronisation of the proof: fetch the proof bytes and the device error word
+    u64 err_word = 0;
+    if (rc == ZK_OK) {
+        if (hipMemcpyAsync(proof_out, d_proof, total * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
+        if (hipMemcpyAsync(&err_word, ctx->d_err, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
+    }
+    hipError_t se = hipStreamSynchronize(ctx->stream);
+    if (se != hipSuccess && rc == ZK_OK) rc = ctx->fail(ZK_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
+    if (rc == ZK_OK && err_word) {
+        rc = (int32_t)(uint32_t)err_word;
+        ctx->fail(rc, "prove: device-side check failed");
+        hipMemsetAsync(ctx->d_err, 0, sizeof(u64), ctx->stream);
+    }
+    cleanup();
+    return rc;
+}

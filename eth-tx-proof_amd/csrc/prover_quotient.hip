@@ -1,0 +1,133 @@
+// Batched constraint-quotient evaluation over the LDE coset.
+// Mirrors starky 0.4.0 prover::compute_quotient_polys + constraint_consumer::ConstraintConsumer +
+// vanishing_poly::eval_vanishing_poly (crate pinned at /root/reference/Cargo.lock:4529-4531).
+// The table's `Stark::eval_packed_generic` body is supplied as data (zk_air: a straight-line program), because the
+// seven zkEVM tables' bodies live in evm_arithmetization 0.1.3 whose source is absent (Cargo.lock:1675-1677).
+//
+// One thread = one point of the coset g*<w_L> in leaf order (position s <-> natural index i = bitrev(s)), so every
+// column read is a coalesced wave access; the "next row" is position bitrev(i + 2^rate_bits), which differs from s
+// only in high bits for all but a vanishing fraction of waves.  Temporaries live in LDS ([reg][thread]); the two
+// alpha-Horner accumulators stay in VGPRs.  Output: quotient values in leaf order, then one inverse DIT NTT gives
+// natural-order coefficients whose n-sized chunks are the quotient polynomials.
+#include "zk_internal.h"
+#include "prover.h"
+
+struct QParams {
+    const zk_instr *instrs; u32 n_instrs, n_regs;
+    const u64 *constants, *pub, *chal, *alphas;
+    const u64 *trace_lde, *aux_lde;
+    u32 C, A, lgL, nch, rate_bits;
+    size_t L;
+    const u64 *lag;            // L_first | L_last on the coset, leaf order
+    const u64 *xA, *xB;        // x_i = g * w_L^i (two-level, natural index)
+    u64 last_inv;              // w_n^-1 : z_last(x) = x - w_n^-1
+    u64 zh_inv[8];             // 1/Z_H on the coset: index i mod 2^rate_bits
+    u64 *out;                  // nch x L, leaf order
+};
+
+__device__ __forceinline__ u64 q_fetch(const QParams &p, u32 o, const u64 *sh, u32 t, size_t s, size_t sn) {
+    u32 kind = o >> 24, idx = o & 0xFFFFFF;
+    switch (kind) {
+    case ZK_OPND_REG: return sh[idx * 256 + t];
+    case ZK_OPND_LOCAL: return idx < p.C ? p.trace_lde[(size_t)idx * p.L + s] : p.aux_lde[(size_t)(idx - p.C) * p.L + s];
+    case ZK_OPND_NEXT: return idx < p.C ? p.trace_lde[(size_t)idx * p.L + sn] : p.aux_lde[(size_t)(idx - p.C) * p.L + sn];
+    case ZK_OPND_CONST: return p.constants[idx];
+    case ZK_OPND_PUBLIC: return p.pub[idx];
+    default: return p.chal[idx];
+    }
+}
+
+__global__ __launch_bounds__(256) void quotient_kernel(QParams p) {
+    extern __shared__ u64 sh[];
+    const u32 t = threadIdx.x;
+    const size_t s = (size_t)blockIdx.x * 256 + t;
+    if (s >= p.L) return;
+    const u32 i = bitrev_u32((u32)s, p.lgL);
+    const size_t sn = bitrev_u32((i + (1u << p.rate_bits)) & (u32)(p.L - 1), p.lgL);
+    const u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);
+    const u64 z_last = gl_sub(x, p.last_inv);
+    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];
+    u64 acc[4] = {0, 0, 0, 0};
+    u64 al[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) al[j] = j < (int)p.nch ? p.alphas[j] : 0;
+    for (u32 pc = 0; pc < p.n_instrs; pc++) {
+        const zk_instr in = p.instrs[pc];
+        u64 a = q_fetch(p, in.a, sh, t, s, sn);
+        if (in.op <= ZK_OP_MUL) {
+            u64 b = q_fetch(p, in.b, sh, t, s, sn);
+            u64 r = in.op == ZK_OP_ADD ? gl_add(a, b) : in.op == ZK_OP_SUB ? gl_sub(a, b) : gl_mul(a, b);
+            sh[(in.dst & 0xFFFFFF) * 256 + t] = r;
+        } else {
+            u64 c = a;
+            if (in.op == ZK_OP_EMIT_TRANSITION) c = gl_mul(a, z_last);
+            else if (in.op == ZK_OP_EMIT_FIRST) c = gl_mul(a, l_first);
+            else if (in.op == ZK_OP_EMIT_LAST) c = gl_mul(a, l_last);
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (j < (int)p.nch) acc[j] = gl_mul_add(acc[j], al[j], c);
+        }
+    }
+    const u64 zi = p.zh_inv[i & ((1u << p.rate_bits) - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (j < (int)p.nch) p.out[(size_t)j * p.L + s] = gl_mul(acc[j], zi);
+}
+
+__global__ void canon_copy_kernel(const u64 *in, u64 *out, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl_canon(in[i]);
+}
+__global__ void set_indicator_kernel(u64 *ind, size_t n) { if (threadIdx.x == 0 && blockIdx.x == 0) { ind[0] = 1; ind[n + n - 1] = 1; } }
+
+// lagrange_first / lagrange_last = PolynomialValues::selector(n, idx).lde_onto_coset(rate_bits), leaf order; cached per size
+static int32_t lagrange_table(zk_ctx *ctx, u32 log_n, u32 rate_bits, u64 **out) {
+    auto key = std::make_pair((int)log_n, (int)rate_bits);
+    auto it = ctx->lagrange_tab.find(key);
+    if (it != ctx->lagrange_tab.end()) { *out = it->second; return ZK_OK; }
+    size_t n = (size_t)1 << log_n, L = n << rate_bits;
+    u64 *ind = (u64 *)ctx->alloc(2 * n * sizeof(u64)), *co = (u64 *)ctx->alloc(2 * n * sizeof(u64)), *tmp = (u64 *)ctx->alloc(2 * n * sizeof(u64));
+    u64 *lde = (u64 *)ctx->alloc(2 * L * sizeof(u64));
+    if (!ind || !co || !tmp || !lde) return ZK_ERR_OOM;
+    hipMemsetAsync(ind, 0, 2 * n * sizeof(u64), ctx->stream);
+    ZK_LAUNCH(ctx, "set_indicator", set_indicator_kernel, dim3(1), dim3(1), 0, ind, n);
+    int32_t rc = zk_ntt_dif(ctx, ind, n, co, n, log_n, 2, 1, nullptr, gl_inv((u64)n % GL_P), 0);
+    for (u32 par = 0; rc == ZK_OK && par < (1u << rate_bits); par++) {
+        u64 shift = gl_mul(GL_GEN, gl_pow(gl_root(log_n + rate_bits), par));
+        TwoLevel pre = zk_scale_table(ctx, shift, 1, log_n);
+        rc = zk_ntt_dit(ctx, co, n, lde + (size_t)bitrev_u32(par, rate_bits) * n, L, log_n, 2, 0, &pre, nullptr, 1, tmp, n);
+    }
+    ctx->release(ind); ctx->release(co); ctx->release(tmp);
+    if (rc != ZK_OK) { ctx->release(lde); return rc; }
+    ctx->lagrange_tab[key] = lde;
+    *out = lde;
+    return ZK_OK;
+}
+
+int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &cfg, const zk_batch *trace, const zk_batch *aux,
+                        const u64 *d_public, const u64 *d_chal, const u64 *d_alphas, u64 *d_qcoeffs) {
+    const u32 log_n = trace->log_n, rate_bits = cfg.rate_bits, lgL = log_n + rate_bits, nch = cfg.num_challenges;
+    const size_t n = (size_t)1 << log_n, L = n << rate_bits;
+    if (nch > 4 || rate_bits > 3) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: num_challenges <= 4, rate_bits <= 3");
+    if (air.host->constraint_degree != 3 || rate_bits != 1)   // quotient_degree_bits == rate_bits == 1
+        return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: only constraint degree 3 with rate_bits 1 is supported");
+    if (air.host->n_regs * 256 * sizeof(u64) > 64 * 1024) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: too many registers");
+    QParams p = {};
+    p.instrs = air.d_instrs; p.n_instrs = air.host->n_instrs; p.n_regs = air.host->n_regs;
+    p.constants = air.d_constants; p.pub = d_public; p.chal = d_chal; p.alphas = d_alphas;
+    p.trace_lde = trace->lde; p.aux_lde = aux ? aux->lde : nullptr;
+    p.C = trace->n_cols; p.A = aux ? aux->n_cols : 0; p.lgL = lgL; p.nch = nch; p.rate_bits = rate_bits; p.L = L;
+    u64 *lag = nullptr;
+    int32_t rc = lagrange_table(ctx, log_n, rate_bits, &lag);
+    if (rc) return rc;
+    p.lag = lag;
+    TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
+    p.xA = xs.A; p.xB = xs.B;
+    p.last_inv = gl_inv(gl_root(log_n));
+    u64 gn = gl_pow(GL_GEN, n), wr = gl_root(rate_bits);
+    for (u32 i = 0; i < (1u << rate_bits); i++) p.zh_inv[i] = gl_inv(gl_sub(gl_mul(gn, gl_pow(wr, i)), 1));
+    p.out = d_qcoeffs;
+    size_t shmem = (size_t)(air.host->n_regs ? air.host->n_regs : 1) * 256 * sizeof(u64);
+    ZK_LAUNCH(ctx, "quotient_eval", quotient_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), shmem, p);
+    // coset_ifft(g): leaf-order values -> natural-order coefficients, scaled by L^-1 g^-j.  In place.
+    TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);
+    return zk_ntt_dit(ctx, d_qcoeffs, L, d_qcoeffs, L, lgL, nch, 1, nullptr, &post, 0, nullptr, 0);
+}

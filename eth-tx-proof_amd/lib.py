@@ -285,3 +285,60 @@ class Challenger:
                 lib().zk_challenger_free(self.h)
         except Exception:
             pass
+
+
+class Table(C.Structure):
+    """zk_table (include/zkgl.h)"""
+    _fields_ = [("air", C.c_void_p), ("log_n", C.c_uint32), ("trace_on_device", C.c_uint32), ("trace", C.c_void_p),
+                ("public_inputs", C.c_void_p)]
+
+
+def _tables(items):
+    """items: (AirProgram, log_n, trace, public_inputs); trace = numpy (n_cols, n) host array, or an int device pointer."""
+    arr = (Table * len(items))()
+    keep = []
+    for i, (prog, log_n, trace, pub) in enumerate(items):
+        pub = _u64(pub)
+        keep.append(pub)
+        arr[i].air = C.cast(prog.ref, C.c_void_p)
+        arr[i].log_n = log_n
+        if isinstance(trace, (int, np.integer)):
+            arr[i].trace_on_device = 1
+            arr[i].trace = int(trace)
+        else:
+            trace = _u64(trace)
+            assert trace.shape == (prog.n_trace_cols, 1 << log_n)
+            keep.append(trace)
+            arr[i].trace_on_device = 0
+            arr[i].trace = trace.ctypes.data
+        arr[i].public_inputs = pub.ctypes.data
+    return arr, keep
+
+
+def proof_size_words(cfg, items):
+    arr, keep = _tables(items)
+    f = lib().zk_proof_size_words
+    f.restype = C.c_size_t
+    return f(C.byref(cfg), C.c_uint32(len(items)), arr)
+
+
+def prove_tables(ctx, cfg, items, out=None):
+    """zk_prove_tables: the STARK proofs of all tables of one unit of work; returns the proof words (numpy uint64)."""
+    arr, keep = _tables(items)
+    n = proof_size_words(cfg, items)
+    if out is None:
+        out = np.empty(n, dtype=np.uint64)
+    ln = C.c_size_t(0)
+    rc = lib().zk_prove_tables(ctx.h, C.byref(cfg), C.c_uint32(len(items)), arr, _p(out), C.c_size_t(out.size), C.byref(ln))
+    ctx._chk(rc, "zk_prove_tables")
+    return out[:ln.value]
+
+
+def synth_trace_dev(ctx, n_cols, log_n, seed, dptr=None):
+    """zk_synth_trace_dev: returns (device pointer, public inputs)."""
+    if dptr is None:
+        dptr = ctx.dev_alloc(8 * n_cols << log_n)
+    pub = np.empty(3, dtype=np.uint64)
+    ctx._chk(lib().zk_synth_trace_dev(ctx.h, C.c_uint32(n_cols), C.c_uint32(log_n), C.c_uint64(seed), C.c_void_p(dptr), _p(pub)),
+             "zk_synth_trace_dev")
+    return dptr, pub

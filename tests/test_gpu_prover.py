@@ -1,0 +1,103 @@
+"""GPU parity for the full unit proof: proof words from the HIP prover == proof words from the CPU oracle (bit exact),
+and the oracle's independent verifier accepts them."""
+import numpy as np
+import pytest
+
+from conftest import P
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+    import eth_tx_proof_amd as E
+    return E.standard_fast_config()
+
+
+@pytest.mark.parametrize("n_cols,n_helpers,log_n", [(6, 2, 6), (7, 0, 5), (5, 1, 10), (93, 19, 8), (9, 3, 12), (21, 4, 13), (1, 0, 4), (12, 9, 9)])
+def test_proof_bit_exact_vs_oracle(ctx, zk, orc, n_cols, n_helpers, log_n):
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(n_cols, n_helpers)
+    tr, pub = orc.synth_trace(n_cols, log_n, 0x5EED0000 + log_n)
+    proof = zk.prove_tables(ctx, cfg, [(prog, log_n, tr, pub)])
+    rc, ref = orc.prove(cfg, [(prog, log_n, tr, pub)])
+    assert rc == 0
+    assert proof.size == ref.size == orc.proof_size_words(cfg, [(prog, log_n, tr, pub)])
+    if not (proof == ref).all():
+        bad = np.nonzero(proof != ref)[0]
+        pytest.fail("first differing word %d of %d (%d differ)" % (bad[0], proof.size, bad.size))
+    assert (proof[2:] < np.uint64(P)).all()
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
+
+
+def test_multi_table_bit_exact(ctx, zk, orc):
+    """cfg4 shape at reduced sizes: several tables, one challenger, tables proved in order"""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    items = []
+    for t, (w, lg, h) in enumerate(((165, 9, 8), (71, 5, 3), (93, 8, 19), (21, 11, 2))):
+        prog = air.cpu_like_air(w, h)
+        tr, pub = orc.synth_trace(w, lg, 0x5EED0000 + 1000 * t)
+        items.append((prog, lg, tr, pub))
+    proof = zk.prove_tables(ctx, cfg, items)
+    rc, ref = orc.prove(cfg, items)
+    assert rc == 0 and (proof == ref).all()
+    assert orc.verify(cfg, [(p, lg, None, pub) for p, lg, _, pub in items], proof) == 0
+
+
+def test_synth_trace_dev_matches_oracle(ctx, zk, orc):
+    for n_cols, log_n in ((93, 10), (7, 6), (2, 5)):
+        d, pub = zk.synth_trace_dev(ctx, n_cols, log_n, 1234)
+        got = ctx.download(d, (n_cols, 1 << log_n))
+        ref, rpub = orc.synth_trace(n_cols, log_n, 1234)
+        assert (got == ref).all() and (pub == rpub).all()
+        ctx.dev_free(d)
+
+
+def test_device_resident_trace_and_determinism(ctx, zk, orc):
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(93, 19)
+    d, pub = zk.synth_trace_dev(ctx, 93, 11, 99)
+    p1 = zk.prove_tables(ctx, cfg, [(prog, 11, d, pub)]).copy()
+    p2 = zk.prove_tables(ctx, cfg, [(prog, 11, d, pub)]).copy()
+    assert (p1 == p2).all()
+    assert orc.verify(cfg, [(prog, 11, None, pub)], p1) == 0
+    tr = ctx.download(d, (93, 1 << 11))
+    rc, ref = orc.prove(cfg, [(prog, 11, tr, pub)])
+    assert rc == 0 and (ref == p1).all()
+    ctx.dev_free(d)
+
+
+def test_unsatisfied_trace_proof_is_rejected(ctx, zk, orc):
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(6, 2)
+    tr, pub = orc.synth_trace(6, 8, 11)
+    tr[2, 17] ^= np.uint64(1)
+    proof = zk.prove_tables(ctx, cfg, [(prog, 8, tr, pub)])
+    assert orc.verify(cfg, [(prog, 8, None, pub)], proof) != 0
+
+
+def test_full_size_unit_proof_verifies(ctx, zk, orc):
+    """BASELINE cfg3 at a size the verifier handles in seconds is 2^16; the 2^20 shape is exercised by bench.py and checked
+    there through the verifier as well (size-independent property: the oracle's verifier accepts the proof)."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(93, 19)
+    d, pub = zk.synth_trace_dev(ctx, 93, 16, 7)
+    proof = zk.prove_tables(ctx, cfg, [(prog, 16, d, pub)])
+    assert orc.verify(cfg, [(prog, 16, None, pub)], proof) == 0
+    ctx.dev_free(d)
+
+
+def test_error_paths(ctx, zk):
+    from eth_tx_proof_amd import air
+    import eth_tx_proof_amd as E
+    cfg = E.standard_fast_config()
+    cfg.rate_bits = 2
+    prog = air.cpu_like_air(6, 0)
+    tr = np.zeros((6, 64), dtype=np.uint64)
+    with pytest.raises(zk.ZkError) as e:
+        zk.prove_tables(ctx, cfg, [(prog, 6, tr, np.zeros(3, dtype=np.uint64))])
+    assert e.value.code == -1
