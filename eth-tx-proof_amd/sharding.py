@@ -1,0 +1,43 @@
+"""Unit sharding across ranks and the final proof hand-off.
+
+Units (= TxProof inputs) are independent (`IndexedStream::from(ir).map(&TxProof)`, /root/reference/leader/src/prover.rs:26-27),
+so rank r proves units r, r+W, r+2W, ...; there is no data-path collective.  Finished proofs are gathered on rank 0,
+where the reference's `fold(&AggProof)` consumes them (prover.rs:28).  Backend: nccl (= RCCL) on GPUs, gloo on CPU.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_units(n_units, world, rank):
+    return list(range(rank, n_units, world))
+
+
+def gather_proofs(local_proofs, n_units, device=None, dst=0):
+    """local_proofs: {unit_index: np.uint64 array (same length for every unit)}.  Returns the list of all proofs in unit
+    order on rank `dst`, None elsewhere."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return [local_proofs[i] for i in range(n_units)]
+    per = (n_units + world - 1) // world
+    plen = len(next(iter(local_proofs.values()))) if local_proofs else 0
+    ln = torch.tensor([plen], dtype=torch.int64, device=device)
+    dist.all_reduce(ln, op=dist.ReduceOp.MAX)
+    plen = int(ln.item())
+    buf = np.zeros((per, plen), dtype=np.uint64)
+    for k, u in enumerate(shard_units(n_units, world, rank)):
+        buf[k] = local_proofs[u]
+    mine = torch.from_numpy(buf.view(np.int64))
+    if device is not None:
+        mine = mine.to(device)
+    out = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, out, dst=dst)
+    if rank != dst:
+        return None
+    res = [None] * n_units
+    for r in range(world):
+        arr = out[r].cpu().numpy().view(np.uint64)
+        for k, u in enumerate(shard_units(n_units, world, r)):
+            res[u] = arr[k].copy()
+    return res
