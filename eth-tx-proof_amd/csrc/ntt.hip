@@ -12,26 +12,12 @@
 //               "bit-reversed coefficients -> bit-reversed evaluations" LDE into coalesced row writes.
 // No pass ever does a global bit-reversal gather: every global access is a run of >= T*8 contiguous bytes.
 #include "zk_internal.h"
+#include <stdlib.h>
 
 #define NTT_MAX_W 10
 #define NTT_LDS_ELEMS 8192   // 64 KiB of LDS per workgroup -> 2 workgroups per CU
 
-struct PassParams {
-    const u64 *in; u64 *out;
-    size_t in_stride, out_stride;   // column strides in elements
-    int k, W, S, TL;                // transform bits, digit bits, stride bits, log2 tile
-    int n_cols;
-    const u64 *tw_digit;            // w_{2^W}^{+-i}, i < 2^(W-1)
-    const u64 *twA, *twB;           // two-level table of w_{2^(W+S)}^{+-x}
-    const u64 *preA, *preB;         // optional input scale table (indexed by coefficient index)
-    const u64 *postA, *postB;       // optional output scale table (indexed by natural output index)
-    u64 post_const;                 // multiply every output (0 = none)
-    int pre_bitrev;                 // pre-scale index = bitrev_k(pos) instead of pos
-    int permute_out;                // DIT last pass: scatter rows to bit-reversed positions
-    int canon_in;                   // canonicalise loaded values
-};
-
-__device__ __forceinline__ u64 tab2(const u64 *A, const u64 *B, u32 x) { return gl_mul(A[x & 2047], B[x >> 11]); }
+#include "ntt_pass.h"
 
 template <bool DIT, bool ROW>
 __global__ __launch_bounds__(256) void ntt_pass_kernel(PassParams p) {
@@ -175,6 +161,20 @@ static u64 *upload(zk_ctx *ctx, const std::vector<u64> &h) {
     return d;
 }
 
+u64 *zk_full_digit_table(zk_ctx *ctx, int W, int inverse) {
+    auto key = std::make_pair(W + 100, inverse);
+    auto it = ctx->digit_tw.find(key);
+    if (it != ctx->digit_tw.end()) return it->second;
+    u64 w = gl_root(W);
+    if (inverse) w = gl_inv(w);
+    std::vector<u64> h((size_t)1 << W);
+    u64 x = 1;
+    for (size_t i = 0; i < h.size(); i++) { h[i] = x; x = gl_mul(x, w); }
+    u64 *d = upload(ctx, h);
+    ctx->digit_tw[key] = d;
+    return d;
+}
+
 u64 *zk_digit_twiddles(zk_ctx *ctx, int W, int inverse) {
     auto key = std::make_pair(W, inverse);
     auto it = ctx->digit_tw.find(key);
@@ -234,7 +234,11 @@ static void digit_widths(int k, int *w, int *np) {
 }
 
 template <bool DIT, bool ROW>
-static void launch_pass(zk_ctx *ctx, const PassParams &p, const char *name) {
+static void launch_pass(zk_ctx *ctx, PassParams &p, const char *name) {
+    if (p.W >= 4 && !getenv("ZK_NTT_SLOW")) {
+        p.tw_full = zk_full_digit_table(ctx, p.W, p.inverse);
+        if (zk_ntt_fast_pass(ctx, p, DIT, ROW, name)) return;
+    }
     size_t n = (size_t)1 << p.k;
     size_t blocks;
     if (ROW) {
@@ -266,7 +270,7 @@ int32_t zk_ntt_dif(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_
         p.k = k; p.W = w[i]; p.S = S; p.n_cols = n_cols;
         bool row = S == 0;
         p.TL = tile_log(w[i], S, row, (((size_t)1 << k) >> w[i]) * (size_t)n_cols);
-        p.tw_digit = zk_digit_twiddles(ctx, w[i], inverse);
+        p.tw_digit = zk_digit_twiddles(ctx, w[i], inverse); p.inverse = inverse;
         if (S > 0) { TwoLevel t = zk_root_table(ctx, w[i] + S, inverse); p.twA = t.A; p.twB = t.B; }
         if (i == 0 && pre) { p.preA = pre->A; p.preB = pre->B; }
         if (i == np - 1) p.post_const = post_const;
@@ -295,7 +299,7 @@ int32_t zk_ntt_dit(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_
         p.k = k; p.W = W; p.S = S; p.n_cols = n_cols;
         bool row = S == 0;
         p.TL = tile_log(W, S, row, (((size_t)1 << k) >> W) * (size_t)n_cols);
-        p.tw_digit = zk_digit_twiddles(ctx, W, inverse);
+        p.tw_digit = zk_digit_twiddles(ctx, W, inverse); p.inverse = inverse;
         if (S > 0) { TwoLevel t = zk_root_table(ctx, W + S, inverse); p.twA = t.A; p.twB = t.B; }
         if (i == 0 && pre) { p.preA = pre->A; p.preB = pre->B; p.pre_bitrev = 1; }
         if (last && post) { p.postA = post->A; p.postB = post->B; }

@@ -1,0 +1,281 @@
+// Register-radix NTT digit pass for gfx950 (the hot NTT kernel).
+// Same contract as ntt.hip's LDS radix-2 pass (PassParams), different execution shape:
+//   * 512 threads, 16 elements per thread held in VGPRs, tile = 8192 elements = 64 KiB of LDS -> 4 waves per SIMD;
+//   * the 2^W-point digit transform (4 <= W <= 10) is done as up to three register phases of radix 16 / 16 / 2^(W-8),
+//     with ONE LDS exchange between phases instead of one LDS round trip + barrier per radix-2 stage;
+//   * global loads/stores are issued in the mapping whose lanes walk contiguous addresses (>= T*8 bytes per run).
+// Phase bookkeeping (slot = position of an element inside the digit, W bits):
+//   H phase: slot bits [W-4, W)   registers i <-> slot i*2^(W-4) + r
+//   M phase: slot bits [P3, P3+P2)
+//   L phase: slot bits [0, P3)
+// DIF (natural digit in, bit-reversed digit out) runs H, M, L; DIT (bit-reversed in, natural out) runs L, M, H.
+// Twiddle between phases: DIF  w_{2^hb}^{e * r}  (hb = slot bits not yet transformed before the phase, r = lower slot bits),
+//                         DIT  w_{2^(W-lo)}^{e * bitrev(upper slot bits)}  (lo = first slot bit of the phase).
+#include "ntt_pass.h"
+
+template <int Q> struct BR { __device__ static constexpr u32 rev(u32 i) { u32 r = 0; for (int b = 0; b < Q; b++) if (i & (1u << b)) r |= 1u << (Q - 1 - b); return r; } };
+
+// radix-2^Q network on registers x[g0 .. g0 + 2^Q); tw16[j] = w_16^j (j < 8) in the pass direction
+template <int Q, bool DIT>
+__device__ __forceinline__ void radix_net(u64 (&x)[16], const int g0, const u64 (&tw16)[8]) {
+    if (Q == 0) return;
+#pragma unroll
+    for (int s = 0; s < Q; s++) {
+        const int h = DIT ? s : (Q - 1 - s);
+#pragma unroll
+        for (int i = 0; i < (1 << Q); i++) {
+            if (i & (1 << h)) continue;
+            const int j = i + (1 << h);
+            const int e = (i & ((1 << h) - 1)) << (Q - 1 - h);      // exponent of w_{2^Q}
+            const int e16 = e << (4 - Q);                           // as a power of w_16
+            u64 u = x[g0 + i], v = x[g0 + j];
+            if (DIT) {
+                if (e16) v = gl_mul(v, tw16[e16]);
+                x[g0 + i] = gl_add(u, v); x[g0 + j] = gl_sub(u, v);
+            } else {
+                x[g0 + i] = gl_add(u, v);
+                u64 d = gl_sub(u, v);
+                x[g0 + j] = e16 ? gl_mul(d, tw16[e16]) : d;
+            }
+        }
+    }
+}
+
+template <bool DIT, bool ROW, int W>
+__global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
+    constexpr int P2 = (W - 4) < 4 ? (W - 4) : 4;
+    constexpr int P3 = W - 4 - P2;
+    constexpr int R = 1 << (W - 4);
+    constexpr int G2 = 16 >> P2, G3 = 16 >> P3;
+    constexpr bool SWZ = ROW && W >= 8;
+    extern __shared__ u64 sh[];
+    const int S = p.S, TL = p.TL;
+    const u32 T = 1u << TL, tid = threadIdx.x;
+    const u32 nact = 1u << (W + TL - 4);
+    const bool act = tid < nact;
+    const size_t n = (size_t)1 << p.k;
+    const u64 *__restrict__ RW = p.tw_full;
+
+    size_t col = 0, base = 0, row0 = 0, rows_per_col = 1, total_rows = 0;
+    if (ROW) { rows_per_col = n >> W; total_rows = rows_per_col * (size_t)p.n_cols; row0 = (size_t)blockIdx.x << TL; }
+    else {
+        size_t tiles_per_block = ((size_t)1 << S) >> TL, tiles_per_col = (n >> (W + S)) * tiles_per_block;
+        col = blockIdx.x / tiles_per_col;
+        size_t rem = blockIdx.x % tiles_per_col;
+        base = ((rem / tiles_per_block) << (W + S)) + ((rem % tiles_per_block) << TL);
+    }
+    u64 tw16[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) tw16[j] = RW[j << (W - 4)];
+
+    auto lds_idx = [&](u32 t, u32 slot) -> u32 {
+        if (ROW) { u32 s2 = SWZ ? (slot ^ ((slot >> (W - 4)) << P3)) : slot; return (t << W) + s2; }
+        return (slot << TL) + t;
+    };
+    // ---- thread <-> (t, slot) for register q in each mapping
+    auto map_H = [&](int q, u32 &t, u32 &slot) {
+        u32 r;
+        if (ROW) { r = tid & (R - 1); t = tid >> (W - 4); } else { t = tid & (T - 1); r = tid >> TL; }
+        slot = (u32)q * R + r;
+    };
+    auto map_M = [&](int q, u32 &t, u32 &slot) {
+        const int g = q >> P2, i = q & ((1 << P2) - 1);
+        u32 c = tid + nact * g, hi, lo;
+        if (ROW) { lo = c & ((1u << P3) - 1); hi = (c >> P3) & 15; t = c >> (P3 + 4); }
+        else { t = c & (T - 1); u32 rest = c >> TL; lo = rest & ((1u << P3) - 1); hi = rest >> P3; }
+        slot = (hi << (P2 + P3)) | ((u32)i << P3) | lo;
+    };
+    auto map_L = [&](int q, u32 &t, u32 &slot) {
+        const int g = q >> P3, i = q & ((1 << P3) - 1);
+        u32 c = tid + nact * g, hb;
+        if (ROW) { hb = c & ((1u << (W - P3)) - 1); t = c >> (W - P3); } else { t = c & (T - 1); hb = c >> TL; }
+        slot = (hb << P3) | (u32)i;
+    };
+    // mapping ids: 0 = H, 1 = M, 2 = L
+    auto map_any = [&](int m, int q, u32 &t, u32 &slot) { if (m == 0) map_H(q, t, slot); else if (m == 1) map_M(q, t, slot); else map_L(q, t, slot); };
+    // global position of (t, slot); returns false when the row is past the end (ROW tail block)
+    auto gpos = [&](u32 t, u32 slot, size_t &c, size_t &pos) -> bool {
+        if (ROW) {
+            size_t rid = row0 + t;
+            if (rid >= total_rows) return false;
+            c = rid / rows_per_col; pos = ((rid % rows_per_col) << W) + slot;
+        } else { c = col; pos = base + ((size_t)slot << S) + t; }
+        return true;
+    };
+
+    u64 x[16];
+    constexpr int FIRST_DIT = P3 > 0 ? 2 : (P2 > 0 ? 1 : 0);     // first phase mapping of DIT == last phase mapping of DIF
+    const int load_map = DIT ? (ROW ? 0 : FIRST_DIT) : 0;
+
+    // ---------------------------------------------------------------- load (+ input scale, + DIT pass pre-twiddle)
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            u32 t, slot; map_any(load_map, q, t, slot);
+            size_t c, pos; u64 v = 0;
+            if (gpos(t, slot, c, pos)) {
+                v = p.in[c * p.in_stride + pos];
+                if (p.canon_in) v = gl_canon(v);
+                if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32((u32)pos, p.k) : (u32)pos; v = gl_mul(v, tab2(p.preA, p.preB, j)); }
+                if (DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); v = gl_mul(v, tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner)); }
+            }
+            x[q] = v;
+        }
+    }
+    auto to_lds = [&](int m) {
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) { u32 t, slot; map_any(m, q, t, slot); sh[lds_idx(t, slot)] = x[q]; }
+        }
+    };
+    auto from_lds = [&](int m) {
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) { u32 t, slot; map_any(m, q, t, slot); x[q] = sh[lds_idx(t, slot)]; }
+        }
+    };
+
+    if (!DIT) {
+        // ------------------------------------------------------------ DIF: H, M, L
+        if (act) {
+            radix_net<4, false>(x, 0, tw16);
+            if (W > 4) {
+                u32 t, slot; map_H(0, t, slot); const u32 r = slot;          // slot of register 0 == r
+#pragma unroll
+                for (int q = 1; q < 16; q++) x[q] = gl_mul(x[q], RW[BR<4>::rev(q) * r]);
+            }
+        }
+        if (P2 > 0) {
+            to_lds(0); __syncthreads(); from_lds(1);
+            if (act) {
+#pragma unroll
+                for (int g = 0; g < G2; g++) radix_net<P2, false>(x, g << P2, tw16);
+                if (P3 > 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int i = q & ((1 << P2) - 1);
+                        if (i == 0) continue;
+                        u32 t, slot; map_M(q, t, slot);
+                        u32 lo = slot & ((1u << P3) - 1);
+                        x[q] = gl_mul(x[q], RW[(BR<P2>::rev(i) * lo) << 4]);
+                    }
+                }
+            }
+        }
+        if (P3 > 0) {
+            to_lds(1); __syncthreads(); from_lds(2);
+            if (act) {
+#pragma unroll
+                for (int g = 0; g < G3; g++) radix_net<P3, false>(x, g << P3, tw16);
+            }
+        }
+    } else {
+        // ------------------------------------------------------------ DIT: L, M, H
+        if (ROW && FIRST_DIT != 0) { to_lds(0); __syncthreads(); from_lds(FIRST_DIT); }
+        if (P3 > 0) {
+            if (act) {
+#pragma unroll
+                for (int g = 0; g < G3; g++) radix_net<P3, true>(x, g << P3, tw16);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int i = q & ((1 << P3) - 1);
+                    if (i == 0) continue;
+                    u32 t, slot; map_L(q, t, slot);
+                    x[q] = gl_mul(x[q], RW[(u32)i * bitrev_u32(slot >> P3, W - P3)]);
+                }
+            }
+            to_lds(2); __syncthreads(); from_lds(1);
+        }
+        if (P2 > 0) {
+            if (act) {
+#pragma unroll
+                for (int g = 0; g < G2; g++) radix_net<P2, true>(x, g << P2, tw16);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int i = q & ((1 << P2) - 1);
+                    if (i == 0) continue;
+                    u32 t, slot; map_M(q, t, slot);
+                    u32 hi = slot >> (P2 + P3);
+                    x[q] = gl_mul(x[q], RW[((u32)i * bitrev_u32(hi, 4)) << P3]);
+                }
+            }
+            to_lds(1); __syncthreads(); from_lds(0);
+        }
+        if (act) radix_net<4, true>(x, 0, tw16);
+    }
+
+    // ---------------------------------------------------------------- store
+    constexpr int LAST_DIF = FIRST_DIT;
+    int smap = DIT ? 0 : LAST_DIF;
+    if (DIT && p.permute_out) {
+        // scatter whole rows to bit-reversed positions: go through LDS so that lanes walk consecutive output positions
+        __syncthreads(); to_lds(0); __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                u32 lin = tid + nact * q;
+                u32 t = lin >> W, pe = lin & ((1u << W) - 1), e = bitrev_u32(pe, W);
+                u64 v = sh[lds_idx(t, e)];
+                size_t c, pos; u32 K;
+                if (ROW) {
+                    size_t rid = row0 + t;
+                    if (rid >= total_rows) continue;
+                    c = rid / rows_per_col; pos = ((rid % rows_per_col) << W) + pe; K = (u32)(((rid % rows_per_col) << W) + e);
+                } else {
+                    c = col;
+                    u32 inner = (u32)(base & (((size_t)1 << S) - 1)) + t;
+                    pos = ((size_t)bitrev_u32(inner, S) << W) + pe; K = (e << S) + inner;
+                }
+                if (p.postA) v = gl_mul(v, tab2(p.postA, p.postB, K));
+                if (p.post_const) v = gl_mul(v, p.post_const);
+                p.out[c * p.out_stride + pos] = v;
+            }
+        }
+        return;
+    }
+    if (!DIT && ROW && LAST_DIF != 0) { __syncthreads(); to_lds(LAST_DIF); __syncthreads(); from_lds(0); smap = 0; }
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            u32 t, slot; map_any(smap, q, t, slot);
+            size_t c, pos;
+            if (!gpos(t, slot, c, pos)) continue;
+            u64 v = x[q];
+            const u32 e = DIT ? slot : bitrev_u32(slot, W);
+            if (!DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); v = gl_mul(v, tab2(p.twA, p.twB, e * inner)); }
+            if (p.postA) {
+                u32 K = ROW ? (u32)(((pos >> W) << W) + e) : (u32)(((base >> (W + S)) << (W + S)) + ((size_t)e << S) + (pos & (((size_t)1 << S) - 1)));
+                v = gl_mul(v, tab2(p.postA, p.postB, K));
+            }
+            if (p.post_const) v = gl_mul(v, p.post_const);
+            p.out[c * p.out_stride + pos] = v;
+        }
+    }
+}
+
+template <bool DIT, bool ROW, int W>
+static void launch_w(zk_ctx *ctx, const PassParams &p, const char *name) {
+    size_t n = (size_t)1 << p.k, blocks;
+    if (ROW) { size_t rows = (n >> p.W) * (size_t)p.n_cols; blocks = (rows + ((size_t)1 << p.TL) - 1) >> p.TL; }
+    else blocks = ((n >> p.W) >> p.TL) * (size_t)p.n_cols;
+    size_t shmem = ((size_t)1 << (p.W + p.TL)) * sizeof(u64);
+    ZK_LAUNCH(ctx, name, (ntt_fast_kernel<DIT, ROW, W>), dim3((unsigned)blocks), dim3(512), shmem, p);
+}
+template <bool DIT, bool ROW>
+static bool launch_dr(zk_ctx *ctx, const PassParams &p, const char *name) {
+    switch (p.W) {
+    case 4: launch_w<DIT, ROW, 4>(ctx, p, name); return true;
+    case 5: launch_w<DIT, ROW, 5>(ctx, p, name); return true;
+    case 6: launch_w<DIT, ROW, 6>(ctx, p, name); return true;
+    case 7: launch_w<DIT, ROW, 7>(ctx, p, name); return true;
+    case 8: launch_w<DIT, ROW, 8>(ctx, p, name); return true;
+    case 9: launch_w<DIT, ROW, 9>(ctx, p, name); return true;
+    case 10: launch_w<DIT, ROW, 10>(ctx, p, name); return true;
+    default: return false;
+    }
+}
+bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p, bool dit, bool row, const char *name) {
+    if (p.W < 4 || p.W > 10 || p.W + p.TL > 13 || !p.tw_full) return false;
+    if (dit) return row ? launch_dr<true, true>(ctx, p, name) : launch_dr<true, false>(ctx, p, name);
+    return row ? launch_dr<false, true>(ctx, p, name) : launch_dr<false, false>(ctx, p, name);
+}

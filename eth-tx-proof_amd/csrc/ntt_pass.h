@@ -1,0 +1,27 @@
+// Parameters of one NTT digit pass, shared by the LDS radix-2 kernel (ntt.hip) and the register-radix kernel (ntt_fast.hip).
+#pragma once
+#include "zk_internal.h"
+
+struct PassParams {
+    const u64 *in; u64 *out;
+    size_t in_stride, out_stride;   // column strides in elements
+    int k, W, S, TL;                // transform bits, digit bits, stride bits, log2 tile
+    int n_cols;
+    const u64 *tw_digit;            // w_{2^W}^{+-i}, i < 2^(W-1)
+    const u64 *tw_full;             // w_{2^W}^{+-i}, i < 2^W  (register-radix kernel)
+    const u64 *twA, *twB;           // two-level table of w_{2^(W+S)}^{+-x}
+    const u64 *preA, *preB;         // optional input scale table (indexed by coefficient index)
+    const u64 *postA, *postB;       // optional output scale table (indexed by natural output index)
+    u64 post_const;                 // multiply every output (0 = none)
+    int pre_bitrev;                 // pre-scale index = bitrev_k(pos) instead of pos
+    int permute_out;                // DIT last pass: scatter rows to bit-reversed positions
+    int canon_in;                   // canonicalise loaded values
+    int inverse;                    // direction (selects the twiddle tables)
+};
+
+__device__ __forceinline__ u64 tab2(const u64 *A, const u64 *B, u32 x) { return gl_mul(A[x & 2047], B[x >> 11]); }
+
+
+// register-radix pass (ntt_fast.hip); returns false when the shape is not covered (caller falls back to the LDS radix-2 kernel)
+bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p, bool dit, bool row, const char *name);
+u64 *zk_full_digit_table(zk_ctx *ctx, int W, int inverse);

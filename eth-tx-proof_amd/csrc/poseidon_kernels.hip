@@ -6,7 +6,7 @@
 // Layout: one thread = one leaf.  Leaves are rows of a column-major matrix, so lane i reads element i of each
 // column: every global load is a fully coalesced 512-byte wave access.  The 12-word sponge state stays in VGPRs.
 #include "zk_internal.h"
-#include "poseidon.cuh"
+#include "poseidon_coop.cuh"
 
 // leaf i = (cols[c*stride + i])_{c < n_cols};  digest -> out[4*i .. 4*i+3]
 __global__ __launch_bounds__(256) void hash_leaves_colmajor_kernel(const u64 *__restrict__ cols, size_t stride, u32 n_cols,
@@ -70,6 +70,18 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64 *__restrict
     ulonglong2 *o = (ulonglong2 *)(parent + 4 * j);
     o[0] = make_ulonglong2(s[0], s[1]);
     o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// small levels: one parent per 16-lane group (lane-cooperative permutation) -- about 7x lower latency than one thread per
+// parent, which is what matters once a level no longer fills the chip
+__global__ __launch_bounds__(256) void merkle_level_coop_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parents) {
+    const int lane = threadIdx.x & 63, l = lane & 15, gb = lane & ~15;
+    size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool live = j < n_parents;
+    u64 s = 0;
+    if (live && l < 8) s = child[8 * j + l];
+    s = psdc::permute16(s, l, gb);
+    if (live && l < 4) parent[4 * j + l] = s;
 }
 
 __global__ __launch_bounds__(256) void permute_batch_kernel(u64 *states, size_t n) {
@@ -137,7 +149,10 @@ int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap
     u64 *cur = levels;
     while (cnt > ((size_t)1 << cap_height)) {
         u64 *nxt = cur + 4 * cnt;
-        ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_kernel, grid1(cnt / 2), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
+        if (cnt / 2 <= 16384)
+            ZK_LAUNCH(ctx, "poseidon_merkle_level_coop", merkle_level_coop_kernel, grid1(cnt / 2 * 16), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
+        else
+            ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_kernel, grid1(cnt / 2), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
         cur = nxt; cnt >>= 1;
     }
     return ZK_OK;

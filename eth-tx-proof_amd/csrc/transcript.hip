@@ -5,37 +5,54 @@
 // The sponge state lives in HBM and is advanced by a tiny kernel on the ctx stream, so caps, openings and challenges
 // never cross PCIe while a proof is being produced; every consumer kernel reads its challenges from device memory.
 #include "zk_internal.h"
-#include "poseidon.cuh"
+#include "poseidon_coop.cuh"
 #include "transcript.h"
 
+// The kernel runs as ONE wave.  The challenger is staged in LDS; every lane executes the (uniform) control flow, lane 0
+// does the bookkeeping writes, and the permutation is the lane-cooperative one (poseidon_coop.cuh): state element l in
+// lane l of each 16-lane group (the four groups compute the same permutation).
 __device__ void ch_duplex(DevChallenger *c) {
-    u64 s[12];
-    for (int i = 0; i < 12; i++) s[i] = c->state[i];
-    for (u32 i = 0; i < c->n_in; i++) s[i] = c->inbuf[i];
-    c->n_in = 0;
-    psd::permute(s);
-    for (int i = 0; i < 12; i++) c->state[i] = s[i];
-    for (int i = 0; i < 8; i++) c->outbuf[i] = s[i];
-    c->n_out = 8;
+    const int lane = threadIdx.x, l = lane & 15, gb = lane & ~15;
+    u64 s = 0;
+    if (l < 12) s = c->state[l];
+    if ((u32)l < c->n_in) s = c->inbuf[l];
+    __syncthreads();
+    s = psdc::permute16(s, l, gb);
+    if (lane < 12) c->state[lane] = s;
+    if (lane < 8) c->outbuf[lane] = s;
+    if (lane == 0) { c->n_in = 0; c->n_out = 8; }
+    __syncthreads();
 }
 __device__ void ch_observe(DevChallenger *c, u64 x) {
-    c->n_out = 0;
-    c->inbuf[c->n_in++] = gl_canon(x);
+    if (threadIdx.x == 0) { c->n_out = 0; c->inbuf[c->n_in] = gl_canon(x); c->n_in = c->n_in + 1; }
+    __syncthreads();
     if (c->n_in == 8) ch_duplex(c);
 }
 __device__ u64 ch_get(DevChallenger *c) {
     if (c->n_in || !c->n_out) ch_duplex(c);
-    return c->outbuf[--c->n_out];
+    u64 v = c->outbuf[c->n_out - 1];
+    __syncthreads();
+    if (threadIdx.x == 0) c->n_out = c->n_out - 1;
+    __syncthreads();
+    return v;
 }
 
-__global__ void transcript_kernel(DevChallenger *c, TOpList ops, u64 *err) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpList ops, u64 *err) {
+    __shared__ DevChallenger L;
+    DevChallenger *c = &L;
+    const int lane = threadIdx.x;
+    {
+        const u64 *src = (const u64 *)gc; u64 *dst = (u64 *)c;
+        for (u32 i = lane; i < sizeof(DevChallenger) / 8; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
     for (int k = 0; k < ops.n; k++) {
         const TOp &o = ops.op[k];
         switch (o.kind) {
         case TOP_INIT:
-            for (int i = 0; i < 12; i++) c->state[i] = 0;
-            c->n_in = 0; c->n_out = 0;
+            if (lane < 12) c->state[lane] = 0;
+            if (lane == 0) { c->n_in = 0; c->n_out = 0; }
+            __syncthreads();
             break;
         case TOP_OBSERVE:
             for (u32 i = 0; i < o.n; i++) ch_observe(c, o.src[i]);
@@ -44,42 +61,49 @@ __global__ void transcript_kernel(DevChallenger *c, TOpList ops, u64 *err) {
             for (u32 i = 0; i < o.n; i++) { ch_observe(c, o.src[i]); ch_observe(c, 0); }
             break;
         case TOP_GET:
-            for (u32 i = 0; i < o.n; i++) o.dst[i] = ch_get(c);
+            for (u32 i = 0; i < o.n; i++) { u64 v = ch_get(c); if (lane == 0) o.dst[i] = v; }
             break;
         case TOP_COMPACT:
             if (c->n_in) ch_duplex(c);
-            c->n_out = 0;
-            if (o.dst) for (int i = 0; i < 12; i++) o.dst[i] = c->state[i];
+            if (lane == 0) c->n_out = 0;
+            __syncthreads();
+            if (o.dst && lane < 12) o.dst[lane] = c->state[lane];
             break;
         case TOP_POW_SETUP: {
             // fri_proof_of_work: duplex_intermediate_state = sponge state with pending inputs written in; dst[12] = witness position
-            for (int i = 0; i < 12; i++) o.dst[i] = c->state[i];
-            for (u32 i = 0; i < c->n_in; i++) o.dst[i] = c->inbuf[i];
-            o.dst[12] = c->n_in;
-            o.dst[13] = ~0ULL;            // best witness so far
+            if (lane < 12) o.dst[lane] = (u32)lane < c->n_in ? c->inbuf[lane] : c->state[lane];
+            if (lane == 0) { o.dst[12] = c->n_in; o.dst[13] = ~0ULL; }    // dst[13] = best witness so far
             break;
         }
         case TOP_POW_FINISH: {
-            u64 w = o.src[13];
-            if (w == ~0ULL) { atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW); w = 0; }
+            u64 w = __hip_atomic_load((u64 *)&o.src[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w == ~0ULL) { if (lane == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW); w = 0; }
             ch_observe(c, w);
             u64 resp = ch_get(c);
-            if ((u32)__clzll((long long)resp) < o.n) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW);
-            o.dst[0] = w;
+            if (lane == 0) {
+                if ((u32)__clzll((long long)resp) < o.n) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW);
+                o.dst[0] = w;
+            }
             break;
         }
         case TOP_GET_INDICES:
             // fri_prover_query_rounds: x_index = challenge.to_canonical_u64() as usize % lde_size (lde_size = 2^o.aux)
-            for (u32 i = 0; i < o.n; i++) o.dst[i] = ch_get(c) & (((u64)1 << o.aux) - 1);
+            for (u32 i = 0; i < o.n; i++) { u64 v = ch_get(c); if (lane == 0) o.dst[i] = v & (((u64)1 << o.aux) - 1); }
             break;
         }
+    }
+    __syncthreads();
+    {
+        const u64 *src = (const u64 *)c; u64 *dst = (u64 *)gc;
+        for (u32 i = lane; i < sizeof(DevChallenger) / 8; i += 64) dst[i] = src[i];
     }
 }
 
 // PoW search: candidate w at state[pos], response = permute(state)[7]; keep the smallest accepted w.
 __global__ __launch_bounds__(256) void pow_grind_kernel(u64 *pow_state /* 14 words */, u64 base, u32 min_zeros) {
     u64 cand = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pow_state[13] < cand) return;       // a smaller witness is already known
+    // a smaller witness is already known: agent-scope load (the per-XCD L2s are not coherent for plain loads)
+    if (__hip_atomic_load(&pow_state[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cand) return;
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = pow_state[i];
@@ -101,7 +125,7 @@ int32_t zk_pow_grind(zk_ctx *ctx, DevChallenger *c, u32 min_zeros, u64 *d_pow_st
     // expected 2^min_zeros candidates; 2^(min_zeros+6) of them fail with probability e^-64.  Later blocks exit early
     // once a smaller witness is recorded.
     u64 total = (u64)1 << (min_zeros + 6 > 40 ? 40 : min_zeros + 6);
-    u64 per_launch = (u64)1 << 22;
+    u64 per_launch = (u64)1 << 17;          // later launches exit at their first instruction once a witness is known
     for (u64 base = 0; base < total; base += per_launch) {
         u64 cnt = total - base < per_launch ? total - base : per_launch;
         ZK_LAUNCH(ctx, "pow_grind", pow_grind_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, d_pow_state, base, min_zeros);
