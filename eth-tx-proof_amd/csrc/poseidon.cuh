@@ -1,9 +1,15 @@
 // Poseidon-Goldilocks permutation for gfx950 (width 12, rate 8, x^7, 4+22+4 rounds).
 // Mirrors plonky2 0.2.2 hash/poseidon.rs `Poseidon::poseidon` + poseidon_goldilocks.rs constants
 // (crate pinned at /root/reference/Cargo.lock:3441-3443; spec and known-answer vectors: SURVEY.md A2).
-// One thread = one permutation, state in VGPRs.  Full rounds use the small-constant circulant MDS on 32-bit
-// halves (v_mad_u64_u32 chains, one reduction per lane); partial rounds use the sparse factorisation
-// M = Sp_i * blockdiag(1, M_hat) derived and verified by tools/gen_constants.py.
+// One thread = one permutation, state in VGPRs.
+//
+// Arithmetic is "weak" inside the permutation: state words are any representative in [0, 2^64) of their residue
+// (as plonky2's own reduce128 returns), which removes every compare-and-select canonicalisation from the inner loops;
+// the 12 outputs are canonicalised once at the end.  On gfx950 every VALU op (v_mad_u64_u32 included) issues at
+// about the same rate (profiles/r01_ubench_int_gfx950.txt), so the cost model is simply the instruction count:
+//   * full rounds: small-constant circulant MDS on 32-bit halves (v_mad_u64_u32 chains, one fold per lane);
+//   * partial rounds: sparse factorisation M = Sp_i * blockdiag(1, M_hat) derived and verified by tools/gen_constants.py,
+//     dot product accumulated in five 32-bit limbs with hardware carry chains (v_addc_co_u32).
 #pragma once
 #include "gl64.cuh"
 
@@ -12,30 +18,68 @@
 
 namespace psd {
 
-__device__ __forceinline__ u64 sbox7(u64 x) {
-    u64 x2 = gl_sqr(x), x3 = gl_mul(x2, x), x4 = gl_sqr(x2);
-    return gl_mul(x3, x4);
+// 64x64 -> 128 with four v_mad_u64_u32 (the running sums never overflow 64 bits)
+__device__ __forceinline__ void mul128(u64 a, u64 b, u64 &lo, u64 &hi) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 A1 = (u64)a0 * b0;
+    u64 A2 = (u64)a0 * b1 + (A1 >> 32);
+    u64 A3 = (u64)a1 * b0 + (u32)A2;
+    u64 A4 = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
+    lo = (A3 << 32) | (u32)A1; hi = A4;
 }
+// weak reduction of hi:lo: lo + h0*eps - h1 with 2^64 = eps, 2^96 = -1; each wrap is repaired by +-eps and cannot wrap twice
+__device__ __forceinline__ u64 wred128(u64 lo, u64 hi) {
+    u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+    u64 t = (u64)h0 * 0xFFFFFFFFu;
+    u64 r1; bool c1 = __builtin_add_overflow(lo, t, &r1);
+    r1 += c1 ? GL_EPS : 0ull;
+    u64 r2; bool b1 = __builtin_sub_overflow(r1, (u64)h1, &r2);
+    r2 -= b1 ? GL_EPS : 0ull;
+    return r2;
+}
+__device__ __forceinline__ u64 wmul(u64 a, u64 b) { u64 lo, hi; mul128(a, b, lo, hi); return wred128(lo, hi); }
+// a*b + c for any 64-bit a, b, c (cannot overflow 128 bits)
+__device__ __forceinline__ u64 wmul_add(u64 a, u64 b, u64 c) {
+    u64 lo, hi; mul128(a, b, lo, hi);
+    u64 l2 = lo + c; hi += (l2 < lo);
+    return wred128(l2, hi);
+}
+// weak a + canonical c: the sum is below 2^64 + p, so one eps repair suffices
+__device__ __forceinline__ u64 wadd_c(u64 a, u64 c) {
+    u64 s; bool cy = __builtin_add_overflow(a, c, &s);
+    return s + (cy ? GL_EPS : 0ull);
+}
+__device__ __forceinline__ u64 wsbox7(u64 x) {
+    u64 x2 = wmul(x, x), x3 = wmul(x2, x), x4 = wmul(x2, x2);
+    return wmul(x3, x4);
+}
+__device__ __forceinline__ u64 sbox7(u64 x) { return gl_canon(wsbox7(x)); }   // canonical in, canonical out
 
-// 3-word accumulator for sums of up to 16 64x64-bit products
-struct acc192 {
-    u64 lo, hi; u32 top;
-    __device__ __forceinline__ void init() { lo = 0; hi = 0; top = 0; }
+// five-limb accumulator for sums of up to 16 products of 64-bit words; carries ride the hardware carry chain
+struct acc160 {
+    u32 l0, l1, l2, l3, l4;
+    __device__ __forceinline__ void init() { l0 = l1 = l2 = l3 = l4 = 0; }
     __device__ __forceinline__ void mac(u64 a, u64 b) {
-        u64 pl = a * b, ph = __umul64hi(a, b);
-        lo += pl;
-        u64 c = lo < pl;
-        u64 h1 = hi + ph;
-        u32 c2 = h1 < ph;
-        u64 h2 = h1 + c;
-        c2 += h2 < h1;
-        hi = h2; top += c2;
+        u64 pl, ph; mul128(a, b, pl, ph);
+        u32 c;
+        l0 = __builtin_addc(l0, (u32)pl, 0u, &c);
+        l1 = __builtin_addc(l1, (u32)(pl >> 32), c, &c);
+        l2 = __builtin_addc(l2, (u32)ph, c, &c);
+        l3 = __builtin_addc(l3, (u32)(ph >> 32), c, &c);
+        l4 += c;
     }
-    // 2^128 = -2^32 (mod p)
-    __device__ __forceinline__ u64 reduce() const { return gl_sub(gl_reduce128(lo, hi), (u64)top << 32); }
+    // value = lo64 + hi64*2^64 + l4*2^128,  2^128 = -2^32 (mod p); l4 < 16.  Weak result.
+    __device__ __forceinline__ u64 reduce() const {
+        u64 r = wred128(((u64)l1 << 32) | l0, ((u64)l3 << 32) | l2);
+        u64 sub = (u64)l4 << 32;
+        u64 d; bool b = __builtin_sub_overflow(r, sub, &d);
+        return d - (b ? GL_EPS : 0ull);
+    }
 };
+// kept under the old name for the lane-cooperative variant
+typedef acc160 acc192;
 
-// out[r] = sum_i s[(i+r)%12]*CIRC[i] + (r==0)*8*s[0],  CIRC = [17,15,41,16,2,28,13,13,39,18,34,20]
+// out[r] = sum_i s[(i+r)%12]*CIRC[i] + (r==0)*8*s[0],  CIRC = [17,15,41,16,2,28,13,13,39,18,34,20]; weak in, weak out
 __device__ __forceinline__ void mds_layer(u64 s[12]) {
     const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u32 lo[12], hi[12];
@@ -50,14 +94,12 @@ __device__ __forceinline__ void mds_layer(u64 s[12]) {
             ah += (u64)hi[(i + r) % 12] * C[i];
         }
         if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
-        // value = al + ah*2^32, al, ah < 2^42
+        // value = al + ah*2^32 with al, ah < 2^42:  low64 + high*2^64, high < 2^11  ->  low + high*eps, one eps repair
         u64 low = al + (ah << 32);
         u64 high = (ah >> 32) + (low < al);
-        // high < 2^11: reduce = low + high*eps with wrap fix
         u64 t1 = (high << 32) - high;
-        u64 r0 = low + t1;
-        if (r0 < t1) r0 += GL_EPS;
-        s[r] = r0 >= GL_P ? r0 - GL_P : r0;
+        u64 r0; bool cy = __builtin_add_overflow(low, t1, &r0);
+        s[r] = r0 + (cy ? GL_EPS : 0ull);
     }
 }
 
@@ -66,19 +108,19 @@ __device__ __forceinline__ void full_rounds(u64 s[12], int first_round) {
     for (int r = 0; r < 4; r++) {
         const u64 *rc = PSD_RC + 12 * (first_round + r);
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], rc[i]));
+        for (int i = 0; i < 12; i++) s[i] = wsbox7(wadd_c(s[i], rc[i]));
         mds_layer(s);
     }
 }
 
 __device__ __forceinline__ void partial_rounds(u64 s[12]) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PSD_PR_FIRST[i]);
+    for (int i = 0; i < 12; i++) s[i] = wadd_c(s[i], PSD_PR_FIRST[i]);
     {   // s[1..] = PR_INIT * s[1..]
         u64 t[11];
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < 11; i++) {
-            acc192 a; a.init();
+            acc160 a; a.init();
 #pragma unroll
             for (int j = 0; j < 11; j++) a.mac(PSD_PR_INIT[11 * i + j], s[1 + j]);
             t[i] = a.reduce();
@@ -88,23 +130,25 @@ __device__ __forceinline__ void partial_rounds(u64 s[12]) {
     }
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
-        u64 s0 = gl_add(sbox7(s[0]), PSD_PR_K[r]);
-        acc192 a; a.init();
+        u64 s0 = wadd_c(wsbox7(s[0]), PSD_PR_K[r]);
+        acc160 a; a.init();
         a.mac(PSD_M00, s0);
         const u64 *vh = PSD_PR_VHAT + 11 * r, *w = PSD_PR_W + 11 * r;
 #pragma unroll
         for (int j = 0; j < 11; j++) a.mac(vh[j], s[1 + j]);
 #pragma unroll
-        for (int j = 0; j < 11; j++) s[1 + j] = gl_mul_add(w[j], s0, s[1 + j]);
+        for (int j = 0; j < 11; j++) s[1 + j] = wmul_add(w[j], s0, s[1 + j]);
         s[0] = a.reduce();
     }
 }
 
-// state must be canonical on entry; canonical on exit
+// any 64-bit representatives in; canonical out
 __device__ __forceinline__ void permute(u64 s[12]) {
     full_rounds(s, 0);
     partial_rounds(s);
     full_rounds(s, 26);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 
 }  // namespace psd

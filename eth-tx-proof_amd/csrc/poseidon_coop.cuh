@@ -36,7 +36,7 @@ __device__ __forceinline__ u64 permute16(u64 s, const int l, const int gb) {
                     u64 sj = shfl64(s, gb + 1 + j);
                     a.mac(PSD_PR_INIT[11 * row + j], sj);
                 }
-                u64 t = a.reduce();
+                u64 t = gl_canon(a.reduce());
                 if (l >= 1) s = t;
             }
 #pragma unroll 1
