@@ -49,14 +49,51 @@ GLD u64 gl_mulhi(u64 a, u64 b) {
     return (u64)(((unsigned __int128)a * b) >> 64);
 #endif
 }
-GLD u64 gl_mul(u64 a, u64 b) { return gl_reduce128(a * b, gl_mulhi(a, b)); }
+// weak product: any representative in [0, 2^64).  Device path: four v_mad_u64_u32 whose running sums never overflow,
+// then lo + h0*eps - h1 (2^64 = eps, 2^96 = -1) where each wrap is repaired by +-eps and cannot wrap twice.
+GLD u64 gl_mul_weak(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 A1 = (u64)a0 * b0;
+    u64 A2 = (u64)a0 * b1 + (A1 >> 32);
+    u64 A3 = (u64)a1 * b0 + (u32)A2;
+    u64 hi = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
+    u64 lo = (A3 << 32) | (u32)A1;
+    u64 t = (u64)(u32)hi * 0xFFFFFFFFu;
+    u64 r1; bool c1 = __builtin_add_overflow(lo, t, &r1);
+    r1 += c1 ? GL_EPS : 0ull;
+    u64 r2; bool b1_ = __builtin_sub_overflow(r1, hi >> 32, &r2);
+    r2 -= b1_ ? GL_EPS : 0ull;
+    return r2;
+#else
+    return gl_reduce128(a * b, gl_mulhi(a, b));
+#endif
+}
+GLD u64 gl_mul(u64 a, u64 b) { return gl_canon(gl_mul_weak(a, b)); }
 GLD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 // a*b + c (c canonical): one reduction
 GLD u64 gl_mul_add(u64 a, u64 b, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 A1 = (u64)a0 * b0;
+    u64 A2 = (u64)a0 * b1 + (A1 >> 32);
+    u64 A3 = (u64)a1 * b0 + (u32)A2;
+    u64 hi = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
+    u64 lo = (A3 << 32) | (u32)A1;
+    u64 l2 = lo + c;
+    hi += (l2 < lo);
+    u64 t = (u64)(u32)hi * 0xFFFFFFFFu;
+    u64 r1; bool c1 = __builtin_add_overflow(l2, t, &r1);
+    r1 += c1 ? GL_EPS : 0ull;
+    u64 r2; bool b1_ = __builtin_sub_overflow(r1, hi >> 32, &r2);
+    r2 -= b1_ ? GL_EPS : 0ull;
+    return gl_canon(r2);
+#else
     u64 lo = a * b, hi = gl_mulhi(a, b);
     u64 l2 = lo + c;
     hi += (l2 < lo);
     return gl_reduce128(l2, hi);
+#endif
 }
 GLD u64 gl_pow(u64 b, u64 e) {
     u64 r = 1;

@@ -12,6 +12,9 @@
 // Twiddle between phases: DIF  w_{2^hb}^{e * r}  (hb = slot bits not yet transformed before the phase, r = lower slot bits),
 //                         DIT  w_{2^(W-lo)}^{e * bitrev(upper slot bits)}  (lo = first slot bit of the phase).
 #include "ntt_pass.h"
+#include <map>
+#include <tuple>
+#include <stdlib.h>
 
 template <int Q> struct BR { __device__ static constexpr u32 rev(u32 i) { u32 r = 0; for (int b = 0; b < Q; b++) if (i & (1u << b)) r |= 1u << (Q - 1 - b); return r; } };
 
@@ -57,11 +60,15 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     const u64 *__restrict__ RW = p.tw_full;
 
     size_t col = 0, base = 0, row0 = 0, rows_per_col = 1, total_rows = 0;
-    if (ROW) { rows_per_col = n >> W; total_rows = rows_per_col * (size_t)p.n_cols; row0 = (size_t)blockIdx.x << TL; }
-    else {
+    if (ROW) {
+        rows_per_col = n >> W; total_rows = rows_per_col * (size_t)p.n_cols;
+        if (p.col_fast) row0 = (size_t)(blockIdx.x % p.n_cols) * rows_per_col + ((size_t)(blockIdx.x / p.n_cols) << TL);
+        else row0 = (size_t)blockIdx.x << TL;
+    } else {
         size_t tiles_per_block = ((size_t)1 << S) >> TL, tiles_per_col = (n >> (W + S)) * tiles_per_block;
-        col = blockIdx.x / tiles_per_col;
-        size_t rem = blockIdx.x % tiles_per_col;
+        size_t rem;
+        if (p.col_fast) { col = blockIdx.x % p.n_cols; rem = blockIdx.x / p.n_cols; }
+        else { col = blockIdx.x / tiles_per_col; rem = blockIdx.x % tiles_per_col; }
         base = ((rem / tiles_per_block) << (W + S)) + ((rem % tiles_per_block) << TL);
     }
     u64 tw16[8];
@@ -116,8 +123,11 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             if (gpos(t, slot, c, pos)) {
                 v = p.in[c * p.in_stride + pos];
                 if (p.canon_in) v = gl_canon(v);
-                if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32((u32)pos, p.k) : (u32)pos; v = gl_mul(v, tab2(p.preA, p.preB, j)); }
-                if (DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); v = gl_mul(v, tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner)); }
+                if (p.load_tab) v = gl_mul(v, p.load_tab[pos]);
+                else {
+                    if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32((u32)pos, p.k) : (u32)pos; v = gl_mul(v, tab2(p.preA, p.preB, j)); }
+                    if (DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); v = gl_mul(v, tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner)); }
+                }
             }
             x[q] = v;
         }
@@ -242,15 +252,53 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             if (!gpos(t, slot, c, pos)) continue;
             u64 v = x[q];
             const u32 e = DIT ? slot : bitrev_u32(slot, W);
-            if (!DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); v = gl_mul(v, tab2(p.twA, p.twB, e * inner)); }
-            if (p.postA) {
-                u32 K = ROW ? (u32)(((pos >> W) << W) + e) : (u32)(((base >> (W + S)) << (W + S)) + ((size_t)e << S) + (pos & (((size_t)1 << S) - 1)));
-                v = gl_mul(v, tab2(p.postA, p.postB, K));
+            if (p.store_tab) v = gl_mul(v, p.store_tab[pos]);
+            else {
+                if (!DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); v = gl_mul(v, tab2(p.twA, p.twB, e * inner)); }
+                if (p.postA) {
+                    u32 K = ROW ? (u32)(((pos >> W) << W) + e) : (u32)(((base >> (W + S)) << (W + S)) + ((size_t)e << S) + (pos & (((size_t)1 << S) - 1)));
+                    v = gl_mul(v, tab2(p.postA, p.postB, K));
+                }
+                if (p.post_const) v = gl_mul(v, p.post_const);
             }
-            if (p.post_const) v = gl_mul(v, p.post_const);
             p.out[c * p.out_stride + pos] = v;
         }
     }
+}
+
+// per-position factor tables: exactly the factors the kernel would otherwise form from two-level tables at run time
+__global__ void build_pass_table_kernel(PassParams p, int dit, int store, u64 *out) {
+    size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)1 << p.k;
+    if (pos >= n) return;
+    const int W = p.W, S = p.S;
+    u32 slot = (u32)((pos >> S) & (((size_t)1 << W) - 1)), inner = (u32)(pos & (((size_t)1 << S) - 1));
+    u64 f = 1;
+    if (!store) {
+        if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32((u32)pos, p.k) : (u32)pos; f = gl_mul(f, tab2(p.preA, p.preB, j)); }
+        if (dit && S > 0) f = gl_mul(f, tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner));
+    } else {
+        u32 e = dit ? slot : bitrev_u32(slot, W);
+        if (!dit && S > 0) f = gl_mul(f, tab2(p.twA, p.twB, e * inner));
+        if (p.postA) f = gl_mul(f, tab2(p.postA, p.postB, (u32)pos));     // DIT output position == natural index
+        if (p.post_const) f = gl_mul(f, p.post_const);
+    }
+    out[pos] = f;
+}
+static const u64 *pass_table(zk_ctx *ctx, const PassParams &p, bool dit, bool store) {
+    if (p.k > 24) return nullptr;                                     // 128 MiB per table beyond this: keep the two-level path
+    char key[192];
+    snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%p.%d.%p.%llx.%d", p.k, p.W, p.S, (int)dit, p.inverse, (const void *)p.preA, p.pre_bitrev,
+             (const void *)p.postA, (unsigned long long)p.post_const, (int)store);
+    auto &cache = ctx->table_cache;
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    size_t n = (size_t)1 << p.k;
+    u64 *t = (u64 *)ctx->alloc(n * sizeof(u64));
+    if (!t) return nullptr;
+    ZK_LAUNCH(ctx, "ntt_build_table", build_pass_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p, (int)dit, (int)store, t);
+    cache[key] = t;
+    return t;
 }
 
 template <bool DIT, bool ROW, int W>
@@ -274,8 +322,20 @@ static bool launch_dr(zk_ctx *ctx, const PassParams &p, const char *name) {
     default: return false;
     }
 }
-bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p, bool dit, bool row, const char *name) {
-    if (p.W < 4 || p.W > 10 || p.W + p.TL > 13 || !p.tw_full) return false;
+bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, const char *name) {
+    if (p0.W < 4 || p0.W > 10 || p0.W + p0.TL > 13 || !p0.tw_full) return false;
+    PassParams p = p0;
+    bool need_load = p.preA || (dit && p.S > 0);
+    bool need_store = !p.permute_out && ((!dit && p.S > 0) || p.postA || p.post_const);
+    // the DIT post table is indexed by the natural output index, which equals the output position only when not permuting
+    static const int use_tab = getenv("ZK_NTT_TAB") ? atoi(getenv("ZK_NTT_TAB")) : 3;       // bit0: ROW passes, bit1: TILE passes
+    static const int use_colfast = getenv("ZK_NTT_COLFAST") ? atoi(getenv("ZK_NTT_COLFAST")) : 3;
+    bool tab_on = row ? (use_tab & 1) : (use_tab & 2);
+    if (need_load && tab_on) p.load_tab = pass_table(ctx, p, dit, false);
+    if (need_store && tab_on) p.store_tab = pass_table(ctx, p, dit, true);
+    size_t rows_per_col = ((size_t)1 << p.k) >> p.W;
+    bool cf_on = row ? (use_colfast & 1) : (use_colfast & 2);
+    p.col_fast = cf_on ? (row ? (rows_per_col >= ((size_t)1 << p.TL) ? 1 : 0) : 1) : 0;
     if (dit) return row ? launch_dr<true, true>(ctx, p, name) : launch_dr<true, false>(ctx, p, name);
     return row ? launch_dr<false, true>(ctx, p, name) : launch_dr<false, false>(ctx, p, name);
 }

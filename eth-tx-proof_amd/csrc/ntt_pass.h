@@ -17,6 +17,10 @@ struct PassParams {
     int permute_out;                // DIT last pass: scatter rows to bit-reversed positions
     int canon_in;                   // canonicalise loaded values
     int inverse;                    // direction (selects the twiddle tables)
+    // register-radix kernel only: every per-position factor of the pass folded into one coalesced table each
+    const u64 *load_tab;            // multiply the element loaded from position pos by load_tab[pos]  (or NULL)
+    const u64 *store_tab;           // multiply the element stored to position pos by store_tab[pos]  (or NULL)
+    int col_fast;                   // blockIdx -> (tile, column) with the column fastest, so table slices stay in L2
 };
 
 __device__ __forceinline__ u64 tab2(const u64 *A, const u64 *B, u32 x) { return gl_mul(A[x & 2047], B[x >> 11]); }

@@ -37,6 +37,7 @@ struct zk_ctx {
     std::map<std::pair<int, int>, TwoLevel> root_tab;              // (m, inverse): w_{2^m}^{+-x}
     std::map<std::tuple<u64, u64, int>, TwoLevel> scale_tab;       // (base, premul, log_count): premul*base^j
     std::map<std::pair<int, int>, u64 *> lagrange_tab;             // (log_n, rate_bits): L_first|L_last on the coset, R order
+    std::map<std::string, u64 *> table_cache;                      // fused per-position NTT pass tables (ntt_fast.hip)
     u64 *d_err = nullptr;                                          // device error word (first error wins)
 
     void *alloc(size_t bytes);
