@@ -219,13 +219,29 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     int smap = DIT ? 0 : LAST_DIF;
     if (DIT && p.permute_out) {
         // scatter whole rows to bit-reversed positions: go through LDS so that lanes walk consecutive output positions
-        __syncthreads(); to_lds(0); __syncthreads();
+        // Exchange layout for the TILE case: element (t, slot) sits at t*2^W + swz(bitrev(slot)), so the read side
+        // (consecutive output positions pe) is linear, and the XOR with the top m = 6-TL address bits and with t spreads the
+        // write side (lanes = t x low bits of r, which land in the TOP bits of bitrev(slot)) over all 64 banks.
+        const int m_sw = 6 - TL;
+        const bool pswz = !ROW && TL <= 6 && (W - m_sw) >= 6;
+        auto pidx = [&](u32 t, u32 a) -> u32 {
+            u32 a2 = a ^ ((a >> (W - m_sw)) & ((1u << m_sw) - 1)) ^ ((t << m_sw) & 63u);
+            return (t << W) + a2;
+        };
+        __syncthreads();
+        if (pswz) {
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) { u32 t, slot; map_H(q, t, slot); sh[pidx(t, bitrev_u32(slot, W))] = x[q]; }
+            }
+        } else to_lds(0);
+        __syncthreads();
         if (act) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 u32 lin = tid + nact * q;
                 u32 t = lin >> W, pe = lin & ((1u << W) - 1), e = bitrev_u32(pe, W);
-                u64 v = sh[lds_idx(t, e)];
+                u64 v = pswz ? sh[pidx(t, pe)] : sh[lds_idx(t, e)];
                 size_t c, pos; u32 K;
                 if (ROW) {
                     size_t rid = row0 + t;

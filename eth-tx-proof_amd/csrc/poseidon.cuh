@@ -79,6 +79,48 @@ struct acc160 {
 // kept under the old name for the lane-cooperative variant
 typedef acc160 acc192;
 
+// Column accumulator for dot products  sum_j const_j * s_j  with wave-uniform constants (SGPR operands).
+// The three 32-bit-aligned product columns (weights 1, 2^32, 2^64) are accumulated separately with v_mad_u64_u32, whose
+// carry-out (an SGPR lane mask the compiler cannot express from C++) is counted by v_addc_co_u32: 8 instructions per term,
+// no carry propagation between columns.  One block = 4 mads then 4 addc, so every carry mask is consumed >= 3
+// instructions after it is produced (gfx950 needs 2 wait states between a VALU SGPR write and its VALU use).
+struct acc3 {
+    u64 c0, c1, c2; u32 o0, o1, o2;
+    __device__ __forceinline__ void init() { c0 = c1 = c2 = 0; o0 = o1 = o2 = 0; }
+    __device__ __forceinline__ void mac_s(u64 a /* wave-uniform */, u64 b) {
+        u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+        u64 k0, k1, k2, k3;
+        asm volatile(
+            "v_mad_u64_u32 %[c0], %[k0], %[a0], %[b0], %[c0]\n\t"
+            "v_mad_u64_u32 %[c1], %[k1], %[a0], %[b1], %[c1]\n\t"
+            "v_mad_u64_u32 %[c2], %[k2], %[a1], %[b1], %[c2]\n\t"
+            "v_mad_u64_u32 %[c1], %[k3], %[a1], %[b0], %[c1]\n\t"
+            "v_addc_co_u32 %[o0], %[k0], 0, %[o0], %[k0]\n\t"
+            "v_addc_co_u32 %[o1], %[k1], 0, %[o1], %[k1]\n\t"
+            "v_addc_co_u32 %[o2], %[k2], 0, %[o2], %[k2]\n\t"
+            "v_addc_co_u32 %[o1], %[k3], 0, %[o1], %[k3]\n\t"
+            : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [o0] "+v"(o0), [o1] "+v"(o1), [o2] "+v"(o2),
+              [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
+            : [a0] "s"(a0), [a1] "s"(a1), [b0] "v"(b0), [b1] "v"(b1));
+    }
+    // value = c0 + c1*2^32 + c2*2^64 + o0*2^64 + o1*2^96 + o2*2^128;  2^64 = eps, 2^96 = -1, 2^128 = -2^32.  Weak result.
+    __device__ __forceinline__ u64 reduce() const {
+        u64 L; bool cL = __builtin_add_overflow(c0, c1 << 32, &L);
+        u64 H1 = c2 + (c1 >> 32);
+        bool w1 = H1 < c2;
+        u64 H = H1 + (cL ? 1 : 0);
+        bool w2 = H < H1;
+        u32 top = o2 + (w1 ? 1 : 0) + (w2 ? 1 : 0);
+        u64 r = wred128(L, H);
+        u64 t = (u64)o0 * 0xFFFFFFFFu;
+        u64 r1; bool cy = __builtin_add_overflow(r, t, &r1);
+        r1 += cy ? GL_EPS : 0ull;
+        u64 sub = (u64)o1 + ((u64)top << 32);
+        u64 r2; bool b = __builtin_sub_overflow(r1, sub, &r2);
+        return r2 - (b ? GL_EPS : 0ull);
+    }
+};
+
 // out[r] = sum_i s[(i+r)%12]*CIRC[i] + (r==0)*8*s[0],  CIRC = [17,15,41,16,2,28,13,13,39,18,34,20]; weak in, weak out
 __device__ __forceinline__ void mds_layer(u64 s[12]) {
     const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
@@ -120,9 +162,9 @@ __device__ __forceinline__ void partial_rounds(u64 s[12]) {
         u64 t[11];
 #pragma unroll
         for (int i = 0; i < 11; i++) {
-            acc160 a; a.init();
+            acc3 a; a.init();
 #pragma unroll
-            for (int j = 0; j < 11; j++) a.mac(PSD_PR_INIT[11 * i + j], s[1 + j]);
+            for (int j = 0; j < 11; j++) a.mac_s(PSD_PR_INIT[11 * i + j], s[1 + j]);
             t[i] = a.reduce();
         }
 #pragma unroll
@@ -131,11 +173,11 @@ __device__ __forceinline__ void partial_rounds(u64 s[12]) {
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
         u64 s0 = wadd_c(wsbox7(s[0]), PSD_PR_K[r]);
-        acc160 a; a.init();
-        a.mac(PSD_M00, s0);
+        acc3 a; a.init();
+        a.c0 = (u64)(u32)s0 * (u32)PSD_M00; a.c1 = (s0 >> 32) * (u32)PSD_M00;      // 25 * s0 in the first two columns
         const u64 *vh = PSD_PR_VHAT + 11 * r, *w = PSD_PR_W + 11 * r;
 #pragma unroll
-        for (int j = 0; j < 11; j++) a.mac(vh[j], s[1 + j]);
+        for (int j = 0; j < 11; j++) a.mac_s(vh[j], s[1 + j]);
 #pragma unroll
         for (int j = 0; j < 11; j++) s[1 + j] = wmul_add(w[j], s0, s[1 + j]);
         s[0] = a.reduce();

@@ -101,3 +101,21 @@ def test_error_paths(ctx, zk):
     with pytest.raises(zk.ZkError) as e:
         zk.prove_tables(ctx, cfg, [(prog, 6, tr, np.zeros(3, dtype=np.uint64))])
     assert e.value.code == -1
+
+
+def test_cfg4_seven_table_shapes(ctx, zk, orc):
+    """BASELINE configs[3]: seven tables at log sizes 15/9/12/14/9/12/17 with the recalled zkEVM widths
+    (165/71/93/2431/430/523/21), one shared challenger; accepted by the oracle's verifier."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    items, ptrs = [], []
+    for t, (w, lg) in enumerate(zip(air.ZKEVM_TABLE_WIDTHS, air.ZKEVM_CFG4_LOG_SIZES)):
+        prog = air.cpu_like_air(w, min(19, w // 4))
+        d, pub = zk.synth_trace_dev(ctx, w, lg, 0x5EED0000 + 1000 * t)
+        items.append((prog, lg, d, pub)); ptrs.append(d)
+    proof = zk.prove_tables(ctx, cfg, items)
+    assert orc.verify(cfg, [(p, lg, None, pub) for p, lg, _, pub in items], proof) == 0
+    bad = proof.copy(); bad[proof.size // 3] ^= np.uint64(1)
+    assert orc.verify(cfg, [(p, lg, None, pub) for p, lg, _, pub in items], bad) != 0
+    for d in ptrs:
+        ctx.dev_free(d)
