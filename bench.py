@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--cols", type=int, default=93)
     ap.add_argument("--helpers", type=int, default=19)
-    ap.add_argument("--inflight", type=int, default=2, help="independent unit proofs in flight per GPU (one stream each)")
+    ap.add_argument("--inflight", type=int, default=4, help="independent unit proofs in flight per GPU (one stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -186,8 +186,22 @@ def main():
         else:
             per_launch = ab * proofs0 / dlaunch                    # algorithmic bytes per launch
             achieved = per_launch / (dms / dlaunch * 1e-3) / 1e9   # GB/s
+        traffic = None
+        try:   # HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["leaf_hash_93cols"]
+            if dname == "poseidon_leaf_hash" and per_launch:
+                traffic = per_launch * pm["pmc_bytes"] / pm["algorithmic_bytes"]
+        except Exception:
+            traffic = None
+        # integer-ALU picture of the same kernel: permutations/s against the VALU-issue bound of the instruction stream
+        perms = proofs0 * (2 * n * (-(-C // 8)) + 2 * n * (-(-A // 8) if A > 4 else 0))
+        alu = None
+        if dname == "poseidon_leaf_hash":
+            alu = {"permutations_per_s": perms / (dms * 1e-3), "valu_instr_per_permutation": 25100,
+                   "note": "SQ counters (profiles/r01_pmc_sq_counters_commit_bench.csv): the kernel issues VALU back to back; "
+                           "at ~3.5 SIMD-cycles per wave-instruction the chip bound is ~1.8e9 permutations/s"}
         roof = {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "alu": alu,
                 "avg_launch_ms": dms / dlaunch, "launches": dlaunch, "algorithmic_bytes_per_launch": per_launch,
                 "share_of_kernel_time": dms / tot_ms,
                 "note": "Poseidon hashing is integer-ALU-bound (about 26k VALU instructions per permutation); the HBM "
