@@ -36,3 +36,25 @@ def test_standard_fast_config(zk):
     zk.lib().zk_stark_config_standard_fast(C.byref(c))
     ref = standard_fast_config()
     assert [getattr(c, f) for f, _ in c._fields_] == [getattr(ref, f) for f, _ in ref._fields_] == [100, 2, 1, 4, 16, 4, 5, 84]
+
+
+def _build_ops_smoke(tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "eth-tx-proof_amd", "csrc")
+    exe = str(tmp_path / "ops_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests", "cpp", "ops_smoke.cpp"), "-o", exe,
+                           "-L" + csrc, "-lzkgl_hip", "-Wl,-rpath," + csrc, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_operator_mirror_builds_and_fails_loudly_without_gpu(zk, tmp_path):
+    """ops.hpp compiles against include/zkgl.h and links the product library; without a GPU TxProof::execute raises
+    FatalError (exit code 1) -- there is no host fallback behind the operator either."""
+    import subprocess, torch
+    exe = _build_ops_smoke(tmp_path)
+    rc = subprocess.run([exe], capture_output=True, text=True)
+    if torch.cuda.device_count() == 0:
+        assert rc.returncode == 1 and "FatalError" in rc.stdout
+    else:
+        assert rc.returncode == 0, rc.stdout

@@ -29,3 +29,11 @@ def test_txproof_execute(orc):
     bad = ops.GenerationInputs([ops.TableInput(prog, 7, tr[:, :64], pub)])
     with pytest.raises((ops.FatalError, AssertionError)):
         ops.TxProof().execute(bad)
+
+
+def test_cpp_operator_mirror_runs(zk, tmp_path):
+    import subprocess
+    from test_abi_cpu import _build_ops_smoke
+    rc = subprocess.run([_build_ops_smoke(tmp_path)], capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stdout + rc.stderr
+    assert "proof words" in rc.stdout
