@@ -119,3 +119,48 @@ def test_cfg4_seven_table_shapes(ctx, zk, orc):
     assert orc.verify(cfg, [(p, lg, None, pub) for p, lg, _, pub in items], bad) != 0
     for d in ptrs:
         ctx.dev_free(d)
+
+
+def test_concurrent_contexts_are_independent(zk, orc):
+    """paladin `--num-workers N` shape: N host threads, one zk_ctx (one HIP stream) each, proving different units at the
+    same time; every proof is bit-identical to the oracle's."""
+    import threading
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(12, 3)
+    jobs = [orc.synth_trace(12, 9 + (k % 2), 100 + k) for k in range(4)]
+    outs, errs = [None] * 4, []
+
+    def work(k):
+        try:
+            c = zk.Context(0)
+            tr, pub = jobs[k]
+            for _ in range(3):
+                outs[k] = zk.prove_tables(c, cfg, [(prog, 9 + (k % 2), tr, pub)]).copy()
+            c.close()
+        except Exception as e:
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    for k in range(4):
+        tr, pub = jobs[k]
+        rc, ref = orc.prove(cfg, [(prog, 9 + (k % 2), tr, pub)])
+        assert rc == 0 and (outs[k] == ref).all()
+
+
+def test_proof_buffer_too_small_and_repeatability(ctx, zk, orc):
+    import ctypes as C
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(6, 2)
+    tr, pub = orc.synth_trace(6, 7, 3)
+    n = zk.proof_size_words(cfg, [(prog, 7, tr, pub)])
+    small = np.empty(n - 1, dtype=np.uint64)
+    with pytest.raises(zk.ZkError) as e:
+        zk.prove_tables(ctx, cfg, [(prog, 7, tr, pub)], out=small)
+    assert e.value.code == -9
+    # the context stays usable after an error, and 30 proofs in a row give the same words (no state leaks between calls)
+    first = zk.prove_tables(ctx, cfg, [(prog, 7, tr, pub)]).copy()
+    for _ in range(30):
+        assert (zk.prove_tables(ctx, cfg, [(prog, 7, tr, pub)]) == first).all()
