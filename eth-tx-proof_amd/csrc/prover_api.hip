@@ -1,0 +1,154 @@
+// Finer-grained C-ABI entry points at the starky / plonky2 trait surface: the pieces zk_prove_tables is
+// made of, callable on their own so that a Rust -sys crate can replace upstream items one at a time.
+//   zk_aux_columns          starky::lookup::lookup_helper_columns + cross_table_lookup::partial_sums
+//   zk_quotient             starky::prover::compute_quotient_polys
+//   zk_pow_grind            plonky2::fri::prover::fri_proof_of_work (the search)
+//   zk_fri_prove_openings   plonky2::fri::oracle::PolynomialBatch::prove_openings -> fri_proof
+// (crates pinned at /root/reference/Cargo.lock:4529-4531 and :3441-3443; reached from /root/reference/ops/src/lib.rs:52)
+#include "zk_internal.h"
+#include "prover.h"
+
+static u32 n_aux_of(const zk_air *air, u32 nch) { return air->n_helpers ? nch * (air->n_helpers + 1) : 0; }
+
+extern "C" {
+
+int32_t zk_aux_columns(zk_ctx *ctx, const zk_air *air, uint32_t num_challenges, const uint64_t *challenges,
+                       const uint64_t *trace, uint32_t log_n, uint64_t *aux_out) {
+    if (!ctx || !air || !challenges || !trace || !aux_out || num_challenges == 0 || num_challenges > 4 || log_n > 26) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    const u32 A = n_aux_of(air, num_challenges);
+    if (!A) return ZK_OK;
+    const size_t n = (size_t)1 << log_n;
+    u64 *d_tr = (u64 *)ctx->alloc(n * air->n_trace_cols * sizeof(u64)), *d_aux = (u64 *)ctx->alloc(n * A * sizeof(u64));
+    u64 *d_ch = (u64 *)ctx->alloc(2 * num_challenges * sizeof(u64));
+    zk_helper_desc *d_h = (zk_helper_desc *)ctx->alloc(air->n_helpers * sizeof(zk_helper_desc));
+    int32_t rc = (d_tr && d_aux && d_ch && d_h) ? ZK_OK : ZK_ERR_OOM;
+    std::vector<u64> ch(challenges, challenges + 2 * num_challenges);
+    for (auto &v : ch) v = gl_canon(v);
+    if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_tr, trace, n * air->n_trace_cols * sizeof(u64));
+    if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_ch, ch.data(), ch.size() * sizeof(u64));
+    if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_h, air->helpers, air->n_helpers * sizeof(zk_helper_desc));
+    // the trace is used as given by the helper kernel: canonicalise it through a commit-free pass
+    if (rc == ZK_OK) rc = zk_aux_columns_dev(ctx, air, d_h, num_challenges, d_ch, d_tr, log_n, d_aux);
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, aux_out, d_aux, n * A * sizeof(u64));
+    u64 err = 0;
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, &err, ctx->d_err, sizeof(u64));
+    if (rc == ZK_OK && err) { rc = (int32_t)(uint32_t)err; hipMemsetAsync(ctx->d_err, 0, sizeof(u64), ctx->stream); }
+    ctx->release(d_tr); ctx->release(d_aux); ctx->release(d_ch); ctx->release(d_h);
+    return rc;
+}
+
+int32_t zk_quotient(zk_ctx *ctx, const zk_stark_config *cfg, const zk_air *air, zk_batch *trace, zk_batch *aux,
+                    const uint64_t *public_inputs, const uint64_t *challenges, const uint64_t *alphas, uint64_t *quotient_coeffs_out) {
+    if (!ctx || !cfg || !air || !trace || !alphas || !quotient_coeffs_out) return ZK_ERR_INVALID_ARG;
+    if (trace->n_cols != air->n_trace_cols || (aux && aux->log_n != trace->log_n)) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    const u32 nch = cfg->num_challenges;
+    const size_t L = trace->L();
+    DevAir da; da.host = air;
+    da.d_instrs = (zk_instr *)ctx->alloc((size_t)(air->n_instrs ? air->n_instrs : 1) * sizeof(zk_instr));
+    da.d_constants = (u64 *)ctx->alloc((size_t)(air->n_constants ? air->n_constants : 1) * sizeof(u64));
+    da.d_helpers = nullptr;
+    u64 *d_pub = (u64 *)ctx->alloc((size_t)(air->n_public_inputs ? air->n_public_inputs : 1) * sizeof(u64));
+    u64 *d_ch = (u64 *)ctx->alloc(16 * sizeof(u64)), *d_al = (u64 *)ctx->alloc(8 * sizeof(u64));
+    u64 *d_q = (u64 *)ctx->alloc((size_t)nch * L * sizeof(u64));
+    int32_t rc = (da.d_instrs && da.d_constants && d_pub && d_ch && d_al && d_q) ? ZK_OK : ZK_ERR_OOM;
+    auto up = [&](void *d, const uint64_t *src, size_t cnt) {
+        if (rc != ZK_OK || !cnt) return;
+        std::vector<u64> c(src, src + cnt);
+        for (auto &v : c) v = gl_canon(v);
+        rc = zk_dev_upload(ctx, d, c.data(), cnt * sizeof(u64));
+    };
+    if (rc == ZK_OK && air->n_instrs) rc = zk_dev_upload(ctx, da.d_instrs, air->instrs, air->n_instrs * sizeof(zk_instr));
+    up(da.d_constants, air->constants, air->n_constants);
+    up(d_pub, public_inputs, public_inputs ? air->n_public_inputs : 0);
+    up(d_ch, challenges, challenges ? 2 * nch : 0);
+    up(d_al, alphas, nch);
+    if (rc == ZK_OK) rc = zk_quotient_dev(ctx, da, *cfg, trace, aux, d_pub, d_ch, d_al, d_q);
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, quotient_coeffs_out, d_q, (size_t)nch * L * sizeof(u64));
+    ctx->release(da.d_instrs); ctx->release(da.d_constants); ctx->release(d_pub); ctx->release(d_ch); ctx->release(d_al); ctx->release(d_q);
+    return rc;
+}
+
+int32_t zk_pow_grind(zk_ctx *ctx, const uint64_t state[12], uint32_t pos, uint32_t min_zeros, uint64_t *witness_out) {
+    if (!ctx || !state || !witness_out || pos >= 8 || min_zeros > 34) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    u64 h[14];
+    for (int i = 0; i < 12; i++) h[i] = gl_canon(state[i]);
+    h[12] = pos; h[13] = ~0ULL;
+    u64 *d = (u64 *)ctx->alloc(16 * sizeof(u64));
+    if (!d) return ZK_ERR_OOM;
+    int32_t rc = zk_dev_upload(ctx, d, h, sizeof h);
+    if (rc == ZK_OK) rc = zk_pow_search_dev(ctx, min_zeros, d);
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, h, d, sizeof h);
+    ctx->release(d);
+    if (rc) return rc;
+    if (h[13] == ~0ULL) return ZK_ERR_POW;
+    *witness_out = h[13];
+    return ZK_OK;
+}
+
+size_t zk_fri_proof_size_words(const zk_stark_config *cfg, uint32_t log_n, uint32_t n_trace_cols, uint32_t n_aux_cols) {
+    if (!cfg) return 0;
+    const u32 capw = 4u << cfg->cap_height, Q = cfg->num_challenges << cfg->rate_bits, lgL = log_n + cfg->rate_bits;
+    u32 ar[64], nl; zk_fri_arities(*cfg, log_n, ar, &nl);
+    u32 d = log_n; for (u32 l = 0; l < nl; l++) d -= ar[l];
+    size_t per_q = (size_t)(n_trace_cols + n_aux_cols + Q) + (size_t)(n_aux_cols ? 3 : 2) * 4 * (lgL - cfg->cap_height);
+    u32 lg = lgL;
+    for (u32 l = 0; l < nl; l++) { lg -= ar[l]; per_q += (2u << ar[l]) + 4 * (size_t)(lg - cfg->cap_height); }
+    return 1 + (size_t)nl * capw + 1 + 2 * ((size_t)1 << d) + 1 + per_q * cfg->num_query_rounds;
+}
+
+int32_t zk_fri_prove_openings(zk_ctx *ctx, const zk_stark_config *cfg, zk_batch *trace, zk_batch *aux, zk_batch *quot,
+                              zk_challenger *ch, const uint64_t zeta[2], uint64_t *fri_proof_out, size_t cap_words, size_t *len_words) {
+    if (!ctx || !cfg || !trace || !quot || !ch || !zeta || !fri_proof_out) return ZK_ERR_INVALID_ARG;
+    if (quot->log_n != trace->log_n || (aux && aux->log_n != trace->log_n) || ch->ctx != ctx) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(ctx->device);
+    const u32 log_n = trace->log_n, nch = cfg->num_challenges, C = trace->n_cols, A = aux ? aux->n_cols : 0, Q = quot->n_cols;
+    const size_t n = trace->n();
+    const size_t fri_words = zk_fri_proof_size_words(cfg, log_n, C, A);
+    if (len_words) *len_words = fri_words;
+    if (cap_words < fri_words) return ZK_ERR_BUFFER_TOO_SMALL;
+    // private proof-shaped buffer: openings first (prove_openings re-derives P(z) from them), then the FRI section
+    FriLayout lay = {};
+    size_t o = 0;
+    lay.o_local = o; o += 2 * (size_t)C; lay.o_next = o; o += 2 * (size_t)C;
+    lay.o_aux = o; o += 2 * (size_t)A; lay.o_auxn = o; o += 2 * (size_t)A;
+    lay.o_zs = o; if (A) o += nch;
+    lay.o_q = o; o += 2 * (size_t)Q;
+    const size_t fri_base = o;
+    u32 ar[64], nl; zk_fri_arities(*cfg, log_n, ar, &nl);
+    const u32 capw = 4u << cfg->cap_height;
+    lay.o_nl = o; o += 1; lay.o_layer_caps = o; o += (size_t)nl * capw;
+    u32 d = log_n; for (u32 l = 0; l < nl; l++) d -= ar[l];
+    lay.o_flen = o; o += 1; lay.o_final = o; o += 2 * ((size_t)1 << d); lay.o_witness = o; o += 1;
+    lay.o_queries = o;
+    lay.per_query = (fri_words - (o - fri_base)) / cfg->num_query_rounds;
+    const size_t total = fri_base + fri_words;
+    u64 *d_buf = (u64 *)ctx->alloc(total * sizeof(u64)), *d_zeta = (u64 *)ctx->alloc(8 * sizeof(u64)), *zs = (u64 *)ctx->alloc(2 * 8 * sizeof(u64));
+    if (!d_buf || !d_zeta || !zs) return ZK_ERR_OOM;
+    u64 g_n = gl_root(log_n);
+    u64 hz[6] = {gl_canon(zeta[0]), gl_canon(zeta[1]), gl_mul(gl_canon(zeta[0]), g_n), gl_mul(gl_canon(zeta[1]), g_n), 1, 0};
+    int32_t rc = zk_dev_upload(ctx, d_zeta, hz, sizeof hz);
+    if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, trace->coeffs, n, log_n, C, d_zeta, d_buf + lay.o_local);
+    if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, trace->coeffs, n, log_n, C, d_zeta + 2, d_buf + lay.o_next);
+    if (rc == ZK_OK && A) rc = zk_eval_cols_at(ctx, aux->coeffs, n, log_n, A, d_zeta, d_buf + lay.o_aux);
+    if (rc == ZK_OK && A) rc = zk_eval_cols_at(ctx, aux->coeffs, n, log_n, A, d_zeta + 2, d_buf + lay.o_auxn);
+    if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, quot->coeffs, n, log_n, Q, d_zeta, d_buf + lay.o_q);
+    if (rc == ZK_OK && A) {
+        rc = zk_eval_cols_at(ctx, aux->coeffs + (size_t)(A - nch) * n, n, log_n, nch, d_zeta + 4, zs);
+        std::vector<u64> tmp(2 * nch), re(nch);
+        if (rc == ZK_OK) rc = zk_dev_download(ctx, tmp.data(), zs, 2 * nch * sizeof(u64));
+        for (u32 j = 0; j < nch; j++) re[j] = tmp[2 * j];
+        if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_buf + lay.o_zs, re.data(), nch * sizeof(u64));
+    }
+    if (rc == ZK_OK) rc = zk_fri_prove_dev(ctx, *cfg, ch->d, trace, aux, quot, d_zeta, d_buf, lay);
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, fri_proof_out, d_buf + fri_base, fri_words * sizeof(u64));
+    u64 err = 0;
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, &err, ctx->d_err, sizeof(u64));
+    if (rc == ZK_OK && err) { rc = (int32_t)(uint32_t)err; hipMemsetAsync(ctx->d_err, 0, sizeof(u64), ctx->stream); }
+    ctx->release(d_buf); ctx->release(d_zeta); ctx->release(zs);
+    return rc;
+}
+
+}  // extern "C"

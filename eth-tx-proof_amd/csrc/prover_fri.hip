@@ -328,7 +328,7 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     // ---- proof of work, query indices
     u64 *d_pow = (u64 *)ctx->alloc(16 * sizeof(u64)), *d_idx = (u64 *)ctx->alloc((size_t)cfg.num_query_rounds * sizeof(u64));
     if (!d_pow || !d_idx) return ZK_ERR_OOM;
-    zk_pow_grind(ctx, ch, cfg.proof_of_work_bits, d_pow, d_proof + lay.o_witness);
+    zk_pow_grind_dev(ctx, ch, cfg.proof_of_work_bits, d_pow, d_proof + lay.o_witness);
     { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET_INDICES; a.op[0].dst = d_idx; a.op[0].n = cfg.num_query_rounds; a.op[0].aux = lgL; zk_transcript_run(ctx, ch, a); }
 
     QueryParams q = {};

@@ -119,9 +119,7 @@ int32_t zk_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops) {
     return ZK_OK;
 }
 
-int32_t zk_pow_grind(zk_ctx *ctx, DevChallenger *c, u32 min_zeros, u64 *d_pow_state, u64 *d_witness_out) {
-    TOpList a = {}; a.n = 1; a.op[0].kind = TOP_POW_SETUP; a.op[0].dst = d_pow_state;
-    zk_transcript_run(ctx, c, a);
+int32_t zk_pow_search_dev(zk_ctx *ctx, u32 min_zeros, u64 *d_pow_state) {
     // expected 2^min_zeros candidates; 2^(min_zeros+6) of them fail with probability e^-64.  Later blocks exit early
     // once a smaller witness is recorded.
     u64 total = (u64)1 << (min_zeros + 6 > 40 ? 40 : min_zeros + 6);
@@ -130,12 +128,17 @@ int32_t zk_pow_grind(zk_ctx *ctx, DevChallenger *c, u32 min_zeros, u64 *d_pow_st
         u64 cnt = total - base < per_launch ? total - base : per_launch;
         ZK_LAUNCH(ctx, "pow_grind", pow_grind_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, d_pow_state, base, min_zeros);
     }
+    return ZK_OK;
+}
+
+int32_t zk_pow_grind_dev(zk_ctx *ctx, DevChallenger *c, u32 min_zeros, u64 *d_pow_state, u64 *d_witness_out) {
+    TOpList a = {}; a.n = 1; a.op[0].kind = TOP_POW_SETUP; a.op[0].dst = d_pow_state;
+    zk_transcript_run(ctx, c, a);
+    zk_pow_search_dev(ctx, min_zeros, d_pow_state);
     TOpList b = {}; b.n = 1; b.op[0].kind = TOP_POW_FINISH; b.op[0].src = d_pow_state; b.op[0].dst = d_witness_out; b.op[0].n = min_zeros;
     zk_transcript_run(ctx, c, b);
     return ZK_OK;
 }
-
-struct zk_challenger { zk_ctx *ctx; DevChallenger *d; u64 *scratch; size_t scratch_words; };
 
 extern "C" {
 

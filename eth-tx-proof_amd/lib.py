@@ -342,3 +342,44 @@ def synth_trace_dev(ctx, n_cols, log_n, seed, dptr=None):
     ctx._chk(lib().zk_synth_trace_dev(ctx.h, C.c_uint32(n_cols), C.c_uint32(log_n), C.c_uint64(seed), C.c_void_p(dptr), _p(pub)),
              "zk_synth_trace_dev")
     return dptr, pub
+
+
+# ---- the pieces of a unit proof (zk_aux_columns, zk_quotient, zk_pow_grind, zk_fri_prove_openings)
+def aux_columns(ctx, prog, challenges, trace, num_challenges=2):
+    trace = _u64(trace)
+    log_n = trace.shape[1].bit_length() - 1
+    ch = _u64(challenges)
+    out = np.empty((prog.n_aux_cols, trace.shape[1]), dtype=np.uint64)
+    ctx._chk(lib().zk_aux_columns(ctx.h, prog.ref, C.c_uint32(num_challenges), _p(ch), _p(trace), C.c_uint32(log_n), _p(out)),
+             "zk_aux_columns")
+    return out
+
+
+def quotient(ctx, cfg, prog, trace_batch, aux_batch, public_inputs, challenges, alphas):
+    n = 1 << trace_batch.log_n
+    out = np.empty((cfg.num_challenges << cfg.rate_bits, n), dtype=np.uint64)
+    pub, ch, al = _u64(public_inputs), _u64(challenges), _u64(alphas)
+    ctx._chk(lib().zk_quotient(ctx.h, C.byref(cfg), prog.ref, trace_batch.h, aux_batch.h if aux_batch is not None else None,
+                               _p(pub), _p(ch), _p(al), _p(out)), "zk_quotient")
+    return out
+
+
+def pow_grind(ctx, state12, pos, min_zeros):
+    st = _u64(state12)
+    w = C.c_uint64(0)
+    ctx._chk(lib().zk_pow_grind(ctx.h, _p(st), C.c_uint32(pos), C.c_uint32(min_zeros), C.byref(w)), "zk_pow_grind")
+    return w.value
+
+
+def fri_prove_openings(ctx, cfg, trace_batch, aux_batch, quot_batch, challenger, zeta):
+    f = lib().zk_fri_proof_size_words
+    f.restype = C.c_size_t
+    n = f(C.byref(cfg), C.c_uint32(trace_batch.log_n), C.c_uint32(trace_batch.n_cols),
+          C.c_uint32(aux_batch.n_cols if aux_batch is not None else 0))
+    out = np.empty(n, dtype=np.uint64)
+    z = _u64(zeta)
+    ln = C.c_size_t(0)
+    ctx._chk(lib().zk_fri_prove_openings(ctx.h, C.byref(cfg), trace_batch.h, aux_batch.h if aux_batch is not None else None,
+                                         quot_batch.h, challenger.h, _p(z), _p(out), C.c_size_t(n), C.byref(ln)),
+             "zk_fri_prove_openings")
+    return out[:ln.value]

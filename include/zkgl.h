@@ -214,6 +214,28 @@ typedef struct {
 size_t zk_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables);
 int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables,
                         uint64_t *proof_out, size_t proof_cap_words, size_t *proof_len_words);
+/* ------------------------------------------------------------------ the pieces of a unit proof, one upstream item each
+ * starky::lookup::lookup_helper_columns + cross_table_lookup::partial_sums: auxiliary columns of one table for the
+ * challenges [beta_0, gamma_0, beta_1, gamma_1, ..] (host in, host out; aux_out = n_aux_cols x 2^log_n column-major,
+ * helper columns of every challenge first, then one Z column per challenge).  ZK_ERR_ZERO_INVERSE if a denominator is 0. */
+int32_t zk_aux_columns(zk_ctx *ctx, const zk_air *air, uint32_t num_challenges, const uint64_t *challenges,
+                       const uint64_t *trace, uint32_t log_n, uint64_t *aux_out);
+/* starky::prover::compute_quotient_polys: (num_challenges << rate_bits) quotient polynomials of 2^log_n coefficients each,
+ * natural coefficient order, column-major (host out).  aux may be NULL.  alphas: num_challenges base-field elements. */
+int32_t zk_quotient(zk_ctx *ctx, const zk_stark_config *cfg, const zk_air *air, zk_batch *trace, zk_batch *aux,
+                    const uint64_t *public_inputs, const uint64_t *challenges, const uint64_t *alphas,
+                    uint64_t *quotient_coeffs_out);
+/* plonky2::fri::prover::fri_proof_of_work: the SMALLEST w such that permute(state with state[pos] = w)[7] has at least
+ * min_zeros leading zero bits (state = the duplex-intermediate sponge state, pos = number of pending inputs). */
+int32_t zk_pow_grind(zk_ctx *ctx, const uint64_t state[12], uint32_t pos, uint32_t min_zeros, uint64_t *witness_out);
+/* plonky2::fri::oracle::PolynomialBatch::prove_openings -> fri_proof on the oracles (trace, aux or NULL, quotient) at zeta:
+ * advances `ch` exactly as upstream does (alpha, per-layer caps and betas, final polynomial, PoW, query indices) and writes
+ * the FriProof words (layout: the "fri:" part of the proof description above). */
+size_t zk_fri_proof_size_words(const zk_stark_config *cfg, uint32_t log_n, uint32_t n_trace_cols, uint32_t n_aux_cols);
+int32_t zk_fri_prove_openings(zk_ctx *ctx, const zk_stark_config *cfg, zk_batch *trace, zk_batch *aux, zk_batch *quot,
+                              zk_challenger *ch, const uint64_t zeta[2], uint64_t *fri_proof_out, size_t cap_words,
+                              size_t *len_words);
+
 /* Synthetic satisfying witness for eth_tx_proof_amd.air.cpu_like_air, generated in HBM;
  * public_inputs_out (host, 3 words, may be NULL) = first-row a0, b0 and last-row a0. */
 int32_t zk_synth_trace_dev(zk_ctx *ctx, uint32_t n_cols, uint32_t log_n, uint64_t seed, uint64_t *d_trace,

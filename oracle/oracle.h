@@ -109,6 +109,12 @@ int32_t orc_prove(const zk_stark_config *cfg, uint32_t n_tables, const orc_table
 /* starky::verifier + plonky2::fri::verifier; trace pointers in `tables` are ignored */
 int32_t orc_verify(const zk_stark_config *cfg, uint32_t n_tables, const orc_table *tables, const uint64_t *proof,
                    size_t proof_len_words);
+/* finer-grained pieces, one per C-ABI entry point of the same name (zk_quotient, zk_pow_grind, zk_fri_prove_openings) */
+int32_t orc_quotient(const zk_stark_config *cfg, const zk_air *air, uint32_t log_n, const orc_batch *trace_b, const orc_batch *aux_b,
+                     const uint64_t *public_inputs, const uint64_t *challenges, const uint64_t *alphas, uint64_t *out);
+int32_t orc_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t min_zeros, uint64_t *witness);
+int32_t orc_fri_prove(const zk_stark_config *cfg, const orc_batch *trace_b, const orc_batch *aux_b, const orc_batch *quot_b,
+                      orc_challenger *ch, const uint64_t zeta[2], uint64_t *out, size_t cap_words, size_t *len_words);
 size_t orc_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const orc_table *tables);
 
 #ifdef __cplusplus

@@ -241,3 +241,30 @@ def verify(cfg, items, proof):
 def proof_size_words(cfg, items):
     arr, keep = _tables(items)
     return lib().orc_proof_size_words(C.byref(cfg), C.c_uint32(len(items)), arr)
+
+
+def quotient(cfg, air_prog, trace_batch, aux_batch, public_inputs, challenges, alphas):
+    n = 1 << trace_batch.log_n
+    out = np.empty((cfg.num_challenges << cfg.rate_bits, n), dtype=np.uint64)
+    pub, ch, al = u64(public_inputs), u64(challenges), u64(alphas)
+    rc = lib().orc_quotient(C.byref(cfg), air_prog.ref, C.c_uint32(trace_batch.log_n), trace_batch.h,
+                            aux_batch.h if aux_batch is not None else None, _p(pub), _p(ch), _p(al), _p(out))
+    assert rc == 0
+    return out
+
+
+def pow_grind(state12, pos, min_zeros):
+    st = u64(state12)
+    w = C.c_uint64(0)
+    rc = lib().orc_pow_grind(_p(st), C.c_uint32(pos), C.c_uint32(min_zeros), C.byref(w))
+    assert rc == 0
+    return w.value
+
+
+def fri_prove(cfg, trace_batch, aux_batch, quot_batch, challenger, zeta, cap_words=1 << 22):
+    out = np.empty(cap_words, dtype=np.uint64)
+    z = u64(zeta)
+    ln = C.c_size_t(0)
+    rc = lib().orc_fri_prove(C.byref(cfg), trace_batch.h, aux_batch.h if aux_batch is not None else None, quot_batch.h,
+                             C.byref(challenger.s), _p(z), _p(out), C.c_size_t(cap_words), C.byref(ln))
+    return rc, out[:ln.value]

@@ -441,3 +441,43 @@ size_t orc_proof_size_words(const zk_stark_config *cfg, uint32_t nt, const orc_t
     }
     return tot;
 }
+
+/* ------------------------------------------------------------ finer-grained entry points (parity tests of the C-ABI pieces) */
+/* starky::prover::compute_quotient_polys: out = (num_challenges << rate_bits) x n coefficients, natural order */
+int32_t orc_quotient(const zk_stark_config *cfg, const zk_air *air, uint32_t log_n, const orc_batch *trace_b, const orc_batch *aux_b,
+                     const uint64_t *public_inputs, const uint64_t *challenges, const uint64_t *alphas, uint64_t *out) {
+    orc_table in = {air, log_n, 0, NULL, public_inputs};
+    tbl_state T; memset(&T, 0, sizeof T);
+    T.in = &in; T.n_aux = aux_b ? aux_b->n_cols : 0; T.trace_b = (orc_batch *)trace_b; T.aux_b = (orc_batch *)aux_b;
+    uint64_t *q = quotient_polys(cfg, &T, challenges, alphas);
+    memcpy(out, q, ((size_t)cfg->num_challenges << (log_n + cfg->rate_bits)) * sizeof(uint64_t));
+    free(q);
+    return ZK_OK;
+}
+/* plonky2::fri::prover::fri_proof_of_work: smallest witness w with leading_zeros(permute(state | w at pos)[7]) >= min_zeros */
+int32_t orc_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t min_zeros, uint64_t *witness) {
+    for (uint64_t c = 0; c < ((uint64_t)1 << 40); c++) {
+        uint64_t s2[12]; memcpy(s2, state, sizeof s2);
+        s2[pos] = c;
+        orc_poseidon(s2);
+        uint64_t r = s2[7];
+        if ((r ? (uint32_t)__builtin_clzll(r) : 64) >= min_zeros) { *witness = c; return ZK_OK; }
+    }
+    return ZK_ERR_POW;
+}
+/* PolynomialBatch::prove_openings + fri_proof for one table: FRI proof words (n_layers ... queries) appended to out */
+int32_t orc_fri_prove(const zk_stark_config *cfg, const orc_batch *trace_b, const orc_batch *aux_b, const orc_batch *quot_b,
+                      orc_challenger *ch, const uint64_t zeta[2], uint64_t *out, size_t cap_words, size_t *len_words) {
+    zk_air air; memset(&air, 0, sizeof air);
+    air.n_trace_cols = trace_b->n_cols;
+    orc_table in = {&air, trace_b->log_n, 0, NULL, NULL};
+    tbl_state T; memset(&T, 0, sizeof T);
+    T.in = &in; T.n_aux = aux_b ? aux_b->n_cols : 0;
+    T.trace_b = (orc_batch *)trace_b; T.aux_b = (orc_batch *)aux_b; T.quot_b = (orc_batch *)quot_b;
+    wr w = {out, cap_words, 0, 0};
+    gl2 z = {gl_canon(zeta[0]), gl_canon(zeta[1])};
+    int32_t rc = fri_prove(cfg, &T, ch, z, &w);
+    if (len_words) *len_words = w.len;
+    if (rc) return rc;
+    return w.overflow ? ZK_ERR_BUFFER_TOO_SMALL : ZK_OK;
+}
