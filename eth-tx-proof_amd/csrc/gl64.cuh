@@ -21,9 +21,10 @@ GLD u64 gl_canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
 
 GLD u64 gl_add(u64 a, u64 b) {
     u64 s = a + b;
-    // carry: true sum = s + 2^64 = s + eps (mod p), and s + eps < p here; no carry: at most one subtraction of p
-    if (s < a) return s + GL_EPS;
-    return s >= GL_P ? s - GL_P : s;
+    // carry: true sum = s + 2^64 = s + eps (mod p), and s + eps < p here; no carry: at most one subtraction of p, and
+    // s - p == s + eps (mod 2^64) -- so both repairs are the same addition, selected without a branch
+    u64 t = s + GL_EPS;
+    return ((s < a) | (s >= GL_P)) ? t : s;
 }
 GLD u64 gl_sub(u64 a, u64 b) {
     u64 d = a - b;
