@@ -74,6 +74,10 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     u64 tw16[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) tw16[j] = RW[j << (W - 4)];
+    // the 2^W digit roots go to LDS behind the tile: the inter-phase twiddles are per-lane gathers, and an LDS gather costs a
+    // fraction of an L1-hit global load's latency
+    u64 *shRW = sh + ((size_t)1 << (W + TL));
+    for (u32 i = tid; i < (1u << W); i += 512) shRW[i] = RW[i];
 
     auto lds_idx = [&](u32 t, u32 slot) -> u32 {
         if (ROW) { u32 s2 = SWZ ? (slot ^ ((slot >> (W - 4)) << P3)) : slot; return (t << W) + s2; }
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             x[q] = v;
         }
     }
+    __syncthreads();            // shRW is complete (the data loads above were in flight meanwhile)
     auto to_lds = [&](int m) {
         if (act) {
 #pragma unroll
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             if (W > 4) {
                 u32 t, slot; map_H(0, t, slot); const u32 r = slot;          // slot of register 0 == r
 #pragma unroll
-                for (int q = 1; q < 16; q++) x[q] = gl_mul(x[q], RW[BR<4>::rev(q) * r]);
+                for (int q = 1; q < 16; q++) x[q] = gl_mul(x[q], shRW[BR<4>::rev(q) * r]);
             }
         }
         if (P2 > 0) {
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                         if (i == 0) continue;
                         u32 t, slot; map_M(q, t, slot);
                         u32 lo = slot & ((1u << P3) - 1);
-                        x[q] = gl_mul(x[q], RW[(BR<P2>::rev(i) * lo) << 4]);
+                        x[q] = gl_mul(x[q], shRW[(BR<P2>::rev(i) * lo) << 4]);
                     }
                 }
             }
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                     const int i = q & ((1 << P3) - 1);
                     if (i == 0) continue;
                     u32 t, slot; map_L(q, t, slot);
-                    x[q] = gl_mul(x[q], RW[(u32)i * bitrev_u32(slot >> P3, W - P3)]);
+                    x[q] = gl_mul(x[q], shRW[(u32)i * bitrev_u32(slot >> P3, W - P3)]);
                 }
             }
             to_lds(2); __syncthreads(); from_lds(1);
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                     if (i == 0) continue;
                     u32 t, slot; map_M(q, t, slot);
                     u32 hi = slot >> (P2 + P3);
-                    x[q] = gl_mul(x[q], RW[((u32)i * bitrev_u32(hi, 4)) << P3]);
+                    x[q] = gl_mul(x[q], shRW[((u32)i * bitrev_u32(hi, 4)) << P3]);
                 }
             }
             to_lds(1); __syncthreads(); from_lds(0);
@@ -322,7 +327,7 @@ static void launch_w(zk_ctx *ctx, const PassParams &p, const char *name) {
     size_t n = (size_t)1 << p.k, blocks;
     if (ROW) { size_t rows = (n >> p.W) * (size_t)p.n_cols; blocks = (rows + ((size_t)1 << p.TL) - 1) >> p.TL; }
     else blocks = ((n >> p.W) >> p.TL) * (size_t)p.n_cols;
-    size_t shmem = ((size_t)1 << (p.W + p.TL)) * sizeof(u64);
+    size_t shmem = (((size_t)1 << (p.W + p.TL)) + ((size_t)1 << p.W)) * sizeof(u64);
     ZK_LAUNCH(ctx, name, (ntt_fast_kernel<DIT, ROW, W>), dim3((unsigned)blocks), dim3(512), shmem, p);
 }
 template <bool DIT, bool ROW>
