@@ -19,6 +19,14 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int mask) {
     return ((u64)hi << 32) | lo;
 }
 
+// rotate within each row of 16 lanes by N (DPP row_ror: VALU latency instead of the LDS-path latency of ds_bpermute)
+template <int N> __device__ __forceinline__ u64 ror16(u64 v) {
+    int lo = (int)(u32)v, hi = (int)(u32)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xF, 0xF, false);
+    return ((u64)(u32)hi << 32) | (u32)lo;
+}
+
 // s: this lane's state element (canonical).  l = lane & 15, gb = lane & ~15.  Lanes with l >= 12 pass s = 0 and ignore the result.
 __device__ __forceinline__ u64 permute16(u64 s, const int l, const int gb) {
     const int lc = l < 12 ? l : 0;                      // clamp table indices of idle lanes
@@ -43,15 +51,16 @@ __device__ __forceinline__ u64 permute16(u64 s, const int l, const int gb) {
             for (int r = 0; r < 22; r++) {
                 u64 s0 = 0;
                 if (l == 0) s0 = gl_add(psd::sbox7(s), PSD_PR_K[r]);
-                s0 = shfl64(s0, gb);
+                // broadcast lane 0 of the group: s0 is zero in the other lanes, so an OR all-reduce over the row does it
+                s0 |= ror16<8>(s0); s0 |= ror16<4>(s0); s0 |= ror16<2>(s0); s0 |= ror16<1>(s0);
                 const int j = lc >= 1 ? lc - 1 : 0;
                 u64 t = l == 0 ? gl_mul(PSD_M00, s0) : gl_mul(PSD_PR_VHAT[11 * r + j], s);
                 if (l >= 12) t = 0;
                 // all-reduce over the 16 lanes of the group
-                t = gl_add(t, shfl_xor64(t, 8));
-                t = gl_add(t, shfl_xor64(t, 4));
-                t = gl_add(t, shfl_xor64(t, 2));
-                t = gl_add(t, shfl_xor64(t, 1));
+                t = gl_add(t, ror16<8>(t));
+                t = gl_add(t, ror16<4>(t));
+                t = gl_add(t, ror16<2>(t));
+                t = gl_add(t, ror16<1>(t));
                 u64 upd = gl_mul_add(PSD_PR_W[11 * r + j], s0, s);
                 s = l == 0 ? t : upd;
             }
