@@ -45,6 +45,16 @@ DEF_KERNEL32(k_perm_b32, asm volatile("v_perm_b32 %0, %1, %0, %2" : "+v"(a[i]) :
 DEF_KERNEL32(k_alignbit, asm volatile("v_alignbit_b32 %0, %1, %0, 7" : "+v"(a[i]) : "v"(b)))
 DEF_KERNEL32(k_add3_u32, asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c)))
 DEF_KERNEL32(k_addc_pair, asm volatile("v_add_co_u32 %0, vcc, %1, %0\n\tv_addc_co_u32 %0, vcc, %2, %0, vcc" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"))
+DEF_KERNEL32(k_mov_b32, asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL32(k_and_b32, asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL32(k_lshlrev_b32, asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i])))
+DEF_KERNEL32(k_cndmask_vcc, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : ))
+DEF_KERNEL32(k_cndmask_e64, asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(b) : "s10", "s11"))
+DEF_KERNEL32(k_add_co_e32, asm volatile("v_add_co_u32 %0, vcc, %1, %0" : "+v"(a[i]) : "v"(b) : "vcc"))
+DEF_KERNEL32(k_sub_u32, asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL32(k_xor_b32, asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL32(k_snop_add, asm volatile("s_nop 1\n\tv_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
+DEF_KERNEL64(k_cmp_lt_u64, asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(a[i]), "v"(b64) : "vcc"))
 DEF_KERNEL64(k_mad_u64_u32, asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc"))
 DEF_KERNEL64(k_lshl_add_u64, asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(a[i]) : "v"(b64)))
 DEF_KERNEL64(k_lshlrev_b64, asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(a[i])))
@@ -65,6 +75,9 @@ int main() {
         {"v_add_u32", k_add_u32, 1}, {"v_add3_u32", k_add3_u32, 1}, {"v_mul_lo_u32", k_mul_lo_u32, 1}, {"v_mul_hi_u32", k_mul_hi_u32, 1},
         {"v_mad_u32_u24", k_mad_u32_u24, 1}, {"v_mul_u32_u24", k_mul_u32_u24, 1}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, 1},
         {"v_dot4_u32_u8", k_dot4_u32_u8, 1}, {"v_dot2_u32_u16", k_dot2_u32_u16, 1}, {"v_perm_b32", k_perm_b32, 1}, {"v_alignbit_b32", k_alignbit, 1},
+        {"v_mov_b32", k_mov_b32, 1}, {"v_and_b32", k_and_b32, 1}, {"v_xor_b32", k_xor_b32, 1}, {"v_sub_u32", k_sub_u32, 1}, {"v_lshlrev_b32", k_lshlrev_b32, 1},
+        {"v_cndmask_b32 (vcc)", k_cndmask_vcc, 1}, {"v_cndmask_b32_e64 (sgpr)", k_cndmask_e64, 1}, {"v_add_co_u32 (vcc out)", k_add_co_e32, 1},
+        {"s_nop 1 + v_add_u32", k_snop_add, 1}, {"v_cmp_lt_u64", k_cmp_lt_u64, 1},
         {"v_add_co+v_addc (64b add)", k_addc_pair, 1}, {"v_mad_u64_u32", k_mad_u64_u32, 1}, {"v_lshl_add_u64", k_lshl_add_u64, 1},
         {"v_lshlrev_b64", k_lshlrev_b64, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_mul_f64", k_mul_f64, 1},
         {"u64 add + carry fix (C++)", k_cmp_cndmask64, 1}, {"__umul64hi + mul (C++)", k_umul64hi, 1},
