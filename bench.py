@@ -165,14 +165,17 @@ def main():
     if errors:
         raise errors[0]
     solo = ctxs[0].profile_report()
-    ctxs[0].profile_reset()
+    for c in ctxs:                       # every stream is profiled over the timed region (same population rocprofv3 sees)
+        c.profile(True)
+        c.profile_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    ctxs[0].profile(False)
+    for c in ctxs:
+        c.profile(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -182,8 +185,12 @@ def main():
     value = units / dt
 
     if rank == 0:
-        rep = ctxs[0].profile_report()           # hipEvent timings of every kernel of ctx 0, over the timed region
-        proofs0 = args.steps                     # unit proofs ctx 0 produced in the timed region
+        rep = {}                                 # hipEvent timings of every kernel of every stream of this rank, timed region
+        for c in ctxs:
+            for k, (l, ms) in c.profile_report().items():
+                a = rep.get(k, (0, 0.0))
+                rep[k] = (a[0] + l, a[1] + ms)
+        proofs0 = args.steps * args.inflight     # unit proofs this rank produced in the timed region
         tot_ms = sum(ms for _, ms in rep.values()) or 1.0
         dname = max(solo.items(), key=lambda kv: kv[1][1])[0]   # dominant kernel = largest total time when run alone
         dlaunch, dms = rep[dname]                                # its launches and hipEvent time over the TIMED region
