@@ -50,6 +50,25 @@ GLD u64 gl_mulhi(u64 a, u64 b) {
     return (u64)(((unsigned __int128)a * b) >> 64);
 #endif
 }
+// lo + h*eps (h a 32-bit value), repaired by +eps when the 64-bit sum wraps (it cannot wrap twice).
+// v_mad_u64_u32 does the multiply-add AND delivers the wrap as an SGPR lane mask (not reachable from C++); the repair is a
+// second v_mad_u64_u32 adding the zero-extended 32-bit mask.  s_nop 1: gfx950 needs two wait states between a VALU SGPR
+// write and its use as a VALU operand.
+__device__ __forceinline__ u64 gl_mad_eps(u32 h, u64 lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r, k; u32 m;
+    asm volatile(
+        "v_mad_u64_u32 %[r], %[k], %[h], -1, %[lo]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %[m], 0, -1, %[k]\n\t"
+        "v_mad_u64_u32 %[r], %[k], %[m], 1, %[r]\n\t"
+        : [r] "=&v"(r), [k] "=&s"(k), [m] "=&v"(m)
+        : [h] "v"(h), [lo] "v"(lo));
+    return r;
+#else
+    return 0;   // host pass only parses device functions
+#endif
+}
 // weak product: any representative in [0, 2^64).  Device path: four v_mad_u64_u32 whose running sums never overflow,
 // then lo + h0*eps - h1 (2^64 = eps, 2^96 = -1) where each wrap is repaired by +-eps and cannot wrap twice.
 GLD u64 gl_mul_weak(u64 a, u64 b) {
@@ -60,9 +79,7 @@ GLD u64 gl_mul_weak(u64 a, u64 b) {
     u64 A3 = (u64)a1 * b0 + (u32)A2;
     u64 hi = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
     u64 lo = (A3 << 32) | (u32)A1;
-    u64 t = (u64)(u32)hi * 0xFFFFFFFFu;
-    u64 r1; bool c1 = __builtin_add_overflow(lo, t, &r1);
-    r1 += c1 ? GL_EPS : 0ull;
+    u64 r1 = gl_mad_eps((u32)hi, lo);
     u64 r2; bool b1_ = __builtin_sub_overflow(r1, hi >> 32, &r2);
     r2 -= b1_ ? GL_EPS : 0ull;
     return r2;
@@ -83,9 +100,7 @@ GLD u64 gl_mul_add(u64 a, u64 b, u64 c) {
     u64 lo = (A3 << 32) | (u32)A1;
     u64 l2 = lo + c;
     hi += (l2 < lo);
-    u64 t = (u64)(u32)hi * 0xFFFFFFFFu;
-    u64 r1; bool c1 = __builtin_add_overflow(l2, t, &r1);
-    r1 += c1 ? GL_EPS : 0ull;
+    u64 r1 = gl_mad_eps((u32)hi, l2);
     u64 r2; bool b1_ = __builtin_sub_overflow(r1, hi >> 32, &r2);
     r2 -= b1_ ? GL_EPS : 0ull;
     return gl_canon(r2);

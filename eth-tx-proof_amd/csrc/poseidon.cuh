@@ -30,9 +30,7 @@ __device__ __forceinline__ void mul128(u64 a, u64 b, u64 &lo, u64 &hi) {
 // weak reduction of hi:lo: lo + h0*eps - h1 with 2^64 = eps, 2^96 = -1; each wrap is repaired by +-eps and cannot wrap twice
 __device__ __forceinline__ u64 wred128(u64 lo, u64 hi) {
     u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
-    u64 t = (u64)h0 * 0xFFFFFFFFu;
-    u64 r1; bool c1 = __builtin_add_overflow(lo, t, &r1);
-    r1 += c1 ? GL_EPS : 0ull;
+    u64 r1 = gl_mad_eps(h0, lo);
     u64 r2; bool b1 = __builtin_sub_overflow(r1, (u64)h1, &r2);
     r2 -= b1 ? GL_EPS : 0ull;
     return r2;
@@ -139,9 +137,7 @@ __device__ __forceinline__ void mds_layer(u64 s[12]) {
         // value = al + ah*2^32 with al, ah < 2^42:  low64 + high*2^64, high < 2^11  ->  low + high*eps, one eps repair
         u64 low = al + (ah << 32);
         u64 high = (ah >> 32) + (low < al);
-        u64 t1 = (high << 32) - high;
-        u64 r0; bool cy = __builtin_add_overflow(low, t1, &r0);
-        s[r] = r0 + (cy ? GL_EPS : 0ull);
+        s[r] = gl_mad_eps((u32)high, low);
     }
 }
 
