@@ -5,4 +5,4 @@ binding plus the mirror of the reference's operator surface (ops.TxProof, /root/
 There is no CPU fallback: loading or creating a context without the HIP library / a GPU raises.
 """
 from . import _abi, air  # noqa: F401
-from ._abi import P, COSET_SHIFT, standard_fast_config  # noqa: F401
+from ._abi import P, COSET_SHIFT, standard_fast_config, standard_recursion_config  # noqa: F401

@@ -42,3 +42,31 @@ def standard_fast_config():
     """StarkConfig::standard_fast_config() -- fixed for the hot path at
     /root/reference/common/src/prover_state/circuit.rs:200-206."""
     return StarkConfig(100, 2, 1, 4, 16, 4, 5, 84)
+
+
+def standard_recursion_config():
+    """FRI / commitment parameters of plonky2's CircuitConfig::standard_recursion_config() (rate_bits 3, cap_height 4, PoW 16,
+    ConstantArityBits(4, 5), 28 query rounds, 2 challenges) -- what the shrink / root / aggregation / block circuits behind
+    /root/reference/ops/src/lib.rs:52,72,95 are proved with; used with zk_fri_prove_instance."""
+    return StarkConfig(100, 2, 3, 4, 16, 4, 5, 28)
+
+
+class FriPoly(C.Structure):
+    _fields_ = [("oracle_index", u32), ("polynomial_index", u32)]
+
+
+class FriBatch(C.Structure):
+    _fields_ = [("point", u64 * 2), ("n_polys", u32), ("reserved", u32), ("polys", C.POINTER(FriPoly))]
+
+
+def fri_instance(batches):
+    """[(point_ext(2), [(oracle_index, polynomial_index), ...]), ...] -> (FriBatch array, keep-alive list)"""
+    arr = (FriBatch * len(batches))()
+    keep = []
+    for i, (pt, polys) in enumerate(batches):
+        pa = (FriPoly * max(1, len(polys)))(*[FriPoly(int(o), int(k)) for o, k in polys])
+        keep.append(pa)
+        arr[i].point[0], arr[i].point[1] = int(pt[0]), int(pt[1])
+        arr[i].n_polys = len(polys)
+        arr[i].polys = C.cast(pa, C.POINTER(FriPoly))
+    return arr, keep

@@ -29,6 +29,14 @@ struct FriLayout {           // offsets (in words) into the proof buffer, per ta
 int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *trace, const zk_batch *aux,
                          const zk_batch *quot, const u64 *d_zeta /* zeta, g*zeta */, u64 *d_proof, const FriLayout &lay);
 
+// fri_proof on final values F (2 columns of L, leaf order); only the o_nl..per_query fields of `lay` are used
+int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, u32 log_n, u64 *F, const zk_batch *const *oracles,
+                         u32 n_oracles, u64 *d_proof, const FriLayout &lay);
+// prove_openings for any FriInstanceInfo: points on the host (canonical), polynomial lists on the host
+struct FriBatchDesc { u64 point[2]; u32 n_polys; const zk_fri_poly *polys; };
+int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *const *oracles, u32 n_oracles,
+                                  const FriBatchDesc *batches, u32 n_batches, u64 *d_proof, const FriLayout &lay);
+
 static inline void zk_fri_arities(const zk_stark_config &cfg, u32 degree_bits, u32 *out, u32 *n_out) {
     u32 d = degree_bits, k = 0;
     while (d > cfg.fri_final_poly_bits && d + cfg.rate_bits - cfg.fri_arity_bits >= cfg.cap_height) { out[k++] = cfg.fri_arity_bits; d -= cfg.fri_arity_bits; }

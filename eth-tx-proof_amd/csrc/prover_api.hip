@@ -151,4 +151,60 @@ int32_t zk_fri_prove_openings(zk_ctx *ctx, const zk_stark_config *cfg, zk_batch 
     return rc;
 }
 
+size_t zk_fri_instance_proof_size_words(const zk_stark_config *cfg, uint32_t log_n, uint32_t n_oracles, const uint32_t *oracle_n_cols) {
+    if (!cfg || !oracle_n_cols || cfg->num_query_rounds == 0) return 0;
+    const u32 capw = 4u << cfg->cap_height, lgL = log_n + cfg->rate_bits;
+    u32 ar[64], nl; zk_fri_arities(*cfg, log_n, ar, &nl);
+    u32 d = log_n; for (u32 l = 0; l < nl; l++) d -= ar[l];
+    size_t per_q = 0;
+    for (u32 o = 0; o < n_oracles; o++) per_q += oracle_n_cols[o] + (size_t)4 * (lgL - cfg->cap_height);
+    u32 lg = lgL;
+    for (u32 l = 0; l < nl; l++) { lg -= ar[l]; per_q += (2u << ar[l]) + 4 * (size_t)(lg - cfg->cap_height); }
+    return 1 + (size_t)nl * capw + 1 + 2 * ((size_t)1 << d) + 1 + per_q * cfg->num_query_rounds;
+}
+
+int32_t zk_fri_prove_instance(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_oracles, zk_batch *const *oracles, uint32_t n_batches,
+                              const zk_fri_batch *batches, zk_challenger *ch, uint64_t *fri_proof_out, size_t cap_words, size_t *len_words) {
+    if (!ctx || !cfg || !oracles || !batches || !ch || !fri_proof_out || ch->ctx != ctx) return ZK_ERR_INVALID_ARG;
+    if (n_oracles == 0 || n_oracles > 8 || n_batches == 0 || n_batches > 4) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: 1..8 oracles, 1..4 batches");
+    if (cfg->rate_bits > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits == 0 || cfg->fri_arity_bits > 6 || cfg->num_query_rounds == 0 ||
+        cfg->proof_of_work_bits > 34)
+        return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: unsupported FRI parameters");
+    u32 ncols[8];
+    for (u32 o = 0; o < n_oracles; o++) {
+        if (!oracles[o] || oracles[o]->ctx != ctx) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: oracle of another context");
+        ncols[o] = oracles[o]->n_cols;
+    }
+    hipSetDevice(ctx->device);
+    const u32 log_n = oracles[0]->log_n;
+    if (log_n + cfg->rate_bits < cfg->cap_height) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: cap_height above the tree");
+    const size_t fri_words = zk_fri_instance_proof_size_words(cfg, log_n, n_oracles, ncols);
+    if (len_words) *len_words = fri_words;
+    if (cap_words < fri_words) return ZK_ERR_BUFFER_TOO_SMALL;
+    FriLayout lay = {};
+    u32 ar[64], nl; zk_fri_arities(*cfg, log_n, ar, &nl);
+    const u32 capw = 4u << cfg->cap_height;
+    size_t o = 0;
+    lay.o_nl = o; o += 1; lay.o_layer_caps = o; o += (size_t)nl * capw;
+    u32 d = log_n; for (u32 l = 0; l < nl; l++) d -= ar[l];
+    lay.o_flen = o; o += 1; lay.o_final = o; o += 2 * ((size_t)1 << d); lay.o_witness = o; o += 1;
+    lay.o_queries = o;
+    lay.per_query = (fri_words - o) / cfg->num_query_rounds;
+    FriBatchDesc desc[4];
+    for (u32 b = 0; b < n_batches; b++) {
+        if (!batches[b].polys) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: batch without polynomials");
+        desc[b].point[0] = gl_canon(batches[b].point[0]); desc[b].point[1] = gl_canon(batches[b].point[1]);
+        desc[b].n_polys = batches[b].n_polys; desc[b].polys = batches[b].polys;
+    }
+    u64 *d_buf = (u64 *)ctx->alloc(fri_words * sizeof(u64));
+    if (!d_buf) return ZK_ERR_OOM;
+    int32_t rc = zk_fri_prove_instance_dev(ctx, *cfg, ch->d, oracles, n_oracles, desc, n_batches, d_buf, lay);
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, fri_proof_out, d_buf, fri_words * sizeof(u64));
+    u64 err = 0;
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, &err, ctx->d_err, sizeof(u64));
+    if (rc == ZK_OK && err) { rc = (int32_t)(uint32_t)err; hipMemsetAsync(ctx->d_err, 0, sizeof(u64), ctx->stream); }
+    ctx->release(d_buf);
+    return rc;
+}
+
 }  // extern "C"

@@ -9,6 +9,7 @@
 //     of a serial synthetic division; the result IS layer 0 of the commit phase, already in leaf order;
 //   * folding is done on natural-order coefficients (contiguous groups of 16), each next layer is one DIF NTT.
 // Extension vectors are stored as two base columns (re | im) so the NTT kernels treat them as a 2-column batch.
+#include <algorithm>
 #include "zk_internal.h"
 #include "prover.h"
 #include "poseidon.cuh"
@@ -190,7 +191,7 @@ __global__ void copy_words_kernel(const u64 *src, u64 *dst, u32 n) {
 
 struct QueryParams {
     u32 n_oracles, n_layers, cap_height, lgL;
-    const u64 *lde[3]; const u64 *levels[3]; u32 n_cols[3];
+    const u64 *lde[8]; const u64 *levels[8]; u32 n_cols[8];
     const u64 *lre[8], *lim[8], *llevels[8]; u32 arity_bits[8];
     const u64 *idx;
     u64 *out; size_t per_query;
@@ -252,8 +253,8 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     u64 *d_apow = (u64 *)ctx->alloc((size_t)(cnt + 2) * 2 * sizeof(u64));
     u64 *d_y = (u64 *)ctx->alloc(6 * sizeof(u64));
     u64 *P = (u64 *)ctx->alloc(6 * n * sizeof(u64)), *Pval = (u64 *)ctx->alloc(6 * L * sizeof(u64)), *tmp = (u64 *)ctx->alloc(6 * n * sizeof(u64));
-    u64 *F = (u64 *)ctx->alloc(2 * L * sizeof(u64)), *Fco = (u64 *)ctx->alloc(2 * L * sizeof(u64));
-    if (!d_alpha || !d_apow || !d_y || !P || !Pval || !tmp || !F || !Fco) return ZK_ERR_OOM;
+    u64 *F = (u64 *)ctx->alloc(2 * L * sizeof(u64));
+    if (!d_alpha || !d_apow || !d_y || !P || !Pval || !tmp || !F) return ZK_ERR_OOM;
     { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_alpha; a.op[0].n = 2; zk_transcript_run(ctx, ch, a); }
     ZK_LAUNCH(ctx, "fri_alpha_pows", alpha_pows_kernel, g1(cnt + 2), dim3(256), 0, (const u64 *)d_alpha, cnt, C + A, nch, d_apow);
     ZK_LAUNCH(ctx, "fri_reduce_openings", reduce_openings_kernel, dim3(nb), dim3(256), 0, (const u64 *)d_proof, lay, C, A, Q, nch, (const u64 *)d_apow, d_y);
@@ -274,7 +275,26 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
     qp.xA = xs.A; qp.xB = xs.B; qp.pts = d_zeta; qp.y = d_y; qp.shifts = d_apow + 2 * cnt; qp.F = F;
     ZK_LAUNCH(ctx, "fri_quotient", fri_quotient_kernel, g1(L), dim3(256), 0, qp);
+    ctx->release(d_alpha); ctx->release(d_apow); ctx->release(d_y); ctx->release(P); ctx->release(Pval); ctx->release(tmp);
 
+    const zk_batch *oracles[3]; u32 no = 0;
+    oracles[no++] = trace; if (A) oracles[no++] = aux; oracles[no++] = quot;
+    rc = zk_fri_proof_dev(ctx, cfg, ch, log_n, F, oracles, no, d_proof, lay);
+    ctx->release(F);
+    return rc;
+}
+
+// plonky2::fri::prover::fri_proof on the final values F (re | im columns of L, leaf order): commit phase, PoW, query rounds
+int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, u32 log_n, u64 *F, const zk_batch *const *oracles,
+                         u32 n_oracles, u64 *d_proof, const FriLayout &lay) {
+    const u32 rate_bits = cfg.rate_bits, lgL = log_n + rate_bits;
+    const size_t L = (size_t)1 << lgL;
+    const u32 capw = 4u << cfg.cap_height;
+    u32 ar[64], nl; zk_fri_arities(cfg, log_n, ar, &nl);
+    if (nl > 8 || n_oracles > 8) return ctx->fail(ZK_ERR_INVALID_ARG, "fri: more than 8 reduction layers or oracles");
+    int32_t rc = ZK_OK;
+    u64 *Fco = (u64 *)ctx->alloc(2 * L * sizeof(u64));
+    if (!Fco) return ZK_ERR_OOM;
     // ---- lde_final_poly coefficients (natural order): coset_ifft(g) of the final values
     {
         TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);
@@ -333,17 +353,171 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
 
     QueryParams q = {};
     q.n_layers = nl; q.cap_height = cfg.cap_height; q.lgL = lgL;
-    u32 no = 0;
-    q.lde[no] = trace->lde; q.levels[no] = trace->levels; q.n_cols[no] = C; no++;
-    if (A) { q.lde[no] = aux->lde; q.levels[no] = aux->levels; q.n_cols[no] = A; no++; }
-    q.lde[no] = quot->lde; q.levels[no] = quot->levels; q.n_cols[no] = Q; no++;
-    q.n_oracles = no;
+    for (u32 o = 0; o < n_oracles; o++) { q.lde[o] = oracles[o]->lde; q.levels[o] = oracles[o]->levels; q.n_cols[o] = oracles[o]->n_cols; }
+    q.n_oracles = n_oracles;
     for (u32 l = 0; l < nl; l++) { q.lre[l] = vre[l]; q.lim[l] = vim[l]; q.llevels[l] = lvl[l]; q.arity_bits[l] = ar[l]; }
     q.idx = d_idx; q.out = d_proof + lay.o_queries; q.per_query = lay.per_query;
     ZK_LAUNCH(ctx, "fri_query_gather", fri_query_kernel, dim3(cfg.num_query_rounds), dim3(256), 0, q);
 
     for (int i = 0; i < n_owned; i++) ctx->release(owned[i]);
-    ctx->release(d_alpha); ctx->release(d_apow); ctx->release(d_y); ctx->release(P); ctx->release(Pval); ctx->release(tmp);
-    ctx->release(F); ctx->release(Fco); ctx->release(d_beta); ctx->release(d_pow); ctx->release(d_idx);
+    ctx->release(Fco); ctx->release(d_beta); ctx->release(d_pow); ctx->release(d_idx);
     return ZK_OK;
+}
+
+// ------------------------------------------------------------------ any FriInstanceInfo (zk_fri_prove_instance)
+#define FRI_MAX_BATCHES 4
+struct GenPows { u32 cnt; u32 sh[FRI_MAX_BATCHES]; };
+// alpha^j for j < cnt, then alpha^sh[b] (the ReducingFactor shift applied before batch b is added)
+__global__ void alpha_pows_gen_kernel(const u64 *alpha, GenPows g, u64 *out) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g.cnt + FRI_MAX_BATCHES) return;
+    gl2 a = gl2_make(alpha[0], alpha[1]);
+    gl2 r = gl2_pow_u32(a, j < g.cnt ? j : g.sh[j - g.cnt]);
+    out[2 * j] = r.a; out[2 * j + 1] = r.b;
+}
+struct CombineGenParams {
+    const u64 *const *cols;            // device array of column pointers, batches back to back
+    u32 start[FRI_MAX_BATCHES], cnt[FRI_MAX_BATCHES];
+    size_t n;
+    const u64 *apow;
+    u64 *P;                            // per batch: re column, im column
+};
+// ReducingFactor::reduce_polys_base, one grid row per batch; coefficient order is whatever the oracles store (bit-reversed)
+__global__ __launch_bounds__(256) void fri_combine_gen_kernel(CombineGenParams p) {
+    size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 b = blockIdx.y;
+    if (pos >= p.n) return;
+    const u64 *const *cols = p.cols + p.start[b];
+    u64 ra = 0, rb = 0;
+    const u32 cnt = p.cnt[b];
+    u32 j = 0;
+    for (; j + 4 <= cnt; j += 4) {
+        u64 v0 = cols[j][pos], v1 = cols[j + 1][pos], v2 = cols[j + 2][pos], v3 = cols[j + 3][pos];
+        ra = gl_add(ra, gl_mul(v0, p.apow[2 * j])); rb = gl_add(rb, gl_mul(v0, p.apow[2 * j + 1]));
+        ra = gl_add(ra, gl_mul(v1, p.apow[2 * j + 2])); rb = gl_add(rb, gl_mul(v1, p.apow[2 * j + 3]));
+        ra = gl_add(ra, gl_mul(v2, p.apow[2 * j + 4])); rb = gl_add(rb, gl_mul(v2, p.apow[2 * j + 5]));
+        ra = gl_add(ra, gl_mul(v3, p.apow[2 * j + 6])); rb = gl_add(rb, gl_mul(v3, p.apow[2 * j + 7]));
+    }
+    for (; j < cnt; j++) {
+        u64 v = cols[j][pos];
+        ra = gl_add(ra, gl_mul(v, p.apow[2 * j])); rb = gl_add(rb, gl_mul(v, p.apow[2 * j + 1]));
+    }
+    p.P[(size_t)(2 * b) * p.n + pos] = ra; p.P[(size_t)(2 * b + 1) * p.n + pos] = rb;
+}
+// P_b(z_b) from the evaluations of its re and im columns: y = ev_re + X * ev_im, X^2 = 7
+__global__ void fri_join_evals_kernel(const u64 *ev, u32 nb, u64 *y) {
+    u32 b = threadIdx.x;
+    if (b >= nb) return;
+    const u64 *e = ev + 4 * b;
+    u64 b7 = e[3];
+    u64 w = gl_add(gl_add(gl_dbl(gl_dbl(b7)), gl_dbl(b7)), b7);
+    y[2 * b] = gl_add(e[0], w); y[2 * b + 1] = gl_add(e[1], e[2]);
+}
+struct QuotGenParams {
+    const u64 *Pval; size_t L; u32 lgL, nb;
+    const u64 *xA, *xB;
+    const u64 *pts;           // z_b (2 words each)
+    const u64 *y;             // P_b(z_b)
+    const u64 *shifts;        // alpha^cnt_b (2 words each)
+    u64 *F;
+};
+// final values F(x) = (..(q_0 a^cnt_1 + q_1) a^cnt_2 + ..)(x),  q_b(x) = (P_b(x) - P_b(z_b)) / (x - z_b); one inversion per point
+__global__ __launch_bounds__(256) void fri_quotient_gen_kernel(QuotGenParams p) {
+    size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= p.L) return;
+    u32 i = bitrev_u32((u32)s, p.lgL);
+    u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);
+    gl2 den[FRI_MAX_BATCHES], num[FRI_MAX_BATCHES], q[FRI_MAX_BATCHES];
+    u64 nrm[FRI_MAX_BATCHES], pre[FRI_MAX_BATCHES];
+    u64 acc = 1;
+#pragma unroll
+    for (int b = 0; b < FRI_MAX_BATCHES; b++) {
+        if (b < (int)p.nb) {
+            den[b] = gl2_make(gl_sub(x, p.pts[2 * b]), gl_neg(p.pts[2 * b + 1]));
+            u64 bb = gl_mul(den[b].b, den[b].b);
+            u64 w7 = gl_add(gl_add(gl_dbl(gl_dbl(bb)), gl_dbl(bb)), bb);
+            nrm[b] = gl_sub(gl_mul(den[b].a, den[b].a), w7);
+            num[b] = gl2_make(gl_sub(p.Pval[(size_t)(2 * b) * p.L + s], p.y[2 * b]), gl_sub(p.Pval[(size_t)(2 * b + 1) * p.L + s], p.y[2 * b + 1]));
+        } else { nrm[b] = 1; den[b] = gl2_make(1, 0); num[b] = gl2_make(0, 0); }
+        pre[b] = acc; acc = gl_mul(acc, nrm[b]);
+    }
+    u64 inv = gl_inv_fermat(acc);
+#pragma unroll
+    for (int b = FRI_MAX_BATCHES - 1; b >= 0; b--) {
+        u64 ninv = gl_mul(inv, pre[b]);
+        inv = gl_mul(inv, nrm[b]);
+        gl2 dinv = gl2_make(gl_mul(den[b].a, ninv), gl_mul(gl_neg(den[b].b), ninv));
+        q[b] = gl2_mul(num[b], dinv);
+    }
+    gl2 F = q[0];
+#pragma unroll
+    for (int b = 1; b < FRI_MAX_BATCHES; b++)
+        if (b < (int)p.nb) F = gl2_add(gl2_mul(F, gl2_make(p.shifts[2 * b], p.shifts[2 * b + 1])), q[b]);
+    p.F[s] = F.a; p.F[p.L + s] = F.b;
+}
+
+int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *const *oracles, u32 n_oracles,
+                                  const FriBatchDesc *batches, u32 nb, u64 *d_proof, const FriLayout &lay) {
+    const u32 log_n = oracles[0]->log_n, rate_bits = cfg.rate_bits, lgL = log_n + rate_bits;
+    const size_t n = (size_t)1 << log_n, L = n << rate_bits;
+    if (nb == 0 || nb > FRI_MAX_BATCHES || n_oracles == 0 || n_oracles > 8) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: 1..4 batches, 1..8 oracles");
+    std::vector<const u64 *> cols;
+    CombineGenParams cp = {};
+    GenPows gp = {};
+    u64 hpts[2 * FRI_MAX_BATCHES] = {};
+    for (u32 b = 0; b < nb; b++) {
+        if (batches[b].n_polys == 0) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: empty batch");
+        cp.start[b] = (u32)cols.size(); cp.cnt[b] = batches[b].n_polys;
+        for (u32 k = 0; k < batches[b].n_polys; k++) {
+            const zk_fri_poly &fp = batches[b].polys[k];
+            if (fp.oracle_index >= n_oracles || fp.polynomial_index >= oracles[fp.oracle_index]->n_cols)
+                return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: polynomial reference out of range");
+            cols.push_back(oracles[fp.oracle_index]->coeffs + (size_t)fp.polynomial_index * n);
+        }
+        gp.cnt = std::max(gp.cnt, batches[b].n_polys);
+        gp.sh[b] = batches[b].n_polys;
+        hpts[2 * b] = batches[b].point[0]; hpts[2 * b + 1] = batches[b].point[1];
+        // the pointwise quotient needs x != z on the LDE coset g*H_L: only a base-field z with (z/g)^L == 1 can collide
+        if (hpts[2 * b + 1] == 0 && gl_pow(gl_mul(hpts[2 * b], gl_inv(GL_GEN)), (u64)L) == 1)
+            return ctx->fail(ZK_ERR_ZETA_IN_SUBGROUP, "fri instance: opening point lies on the LDE coset");
+    }
+    for (u32 o = 0; o < n_oracles; o++)
+        if (oracles[o]->log_n != log_n || oracles[o]->rate_bits != rate_bits || oracles[o]->cap_height != cfg.cap_height)
+            return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: oracles must share log_n and the config's rate_bits / cap_height");
+    int32_t rc = ZK_OK;
+    u64 *d_alpha = (u64 *)ctx->alloc(2 * sizeof(u64));
+    u64 *d_apow = (u64 *)ctx->alloc((size_t)(gp.cnt + FRI_MAX_BATCHES) * 2 * sizeof(u64));
+    u64 *d_pts = (u64 *)ctx->alloc(2 * FRI_MAX_BATCHES * sizeof(u64)), *d_ev = (u64 *)ctx->alloc(4 * FRI_MAX_BATCHES * sizeof(u64));
+    u64 *d_y = (u64 *)ctx->alloc(2 * FRI_MAX_BATCHES * sizeof(u64));
+    const u64 **d_cols = (const u64 **)ctx->alloc(cols.size() * sizeof(u64 *));
+    u64 *P = (u64 *)ctx->alloc(2 * nb * n * sizeof(u64)), *Pval = (u64 *)ctx->alloc(2 * nb * L * sizeof(u64)), *tmp = (u64 *)ctx->alloc(2 * nb * n * sizeof(u64));
+    u64 *F = (u64 *)ctx->alloc(2 * L * sizeof(u64));
+    if (!d_alpha || !d_apow || !d_pts || !d_ev || !d_y || !d_cols || !P || !Pval || !tmp || !F) return ZK_ERR_OOM;
+    rc = zk_dev_upload(ctx, d_pts, hpts, sizeof hpts);
+    if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_cols, cols.data(), cols.size() * sizeof(u64 *));
+    if (rc) return rc;
+    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_alpha; a.op[0].n = 2; zk_transcript_run(ctx, ch, a); }
+    ZK_LAUNCH(ctx, "fri_alpha_pows", alpha_pows_gen_kernel, g1(gp.cnt + FRI_MAX_BATCHES), dim3(256), 0, (const u64 *)d_alpha, gp, d_apow);
+    cp.cols = d_cols; cp.n = n; cp.apow = d_apow; cp.P = P;
+    ZK_LAUNCH(ctx, "fri_combine", fri_combine_gen_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, cp);
+    // P_b(z_b): what divide_by_linear drops as the remainder
+    for (u32 b = 0; rc == ZK_OK && b < nb; b++) rc = zk_eval_cols_at(ctx, P + (size_t)2 * b * n, n, log_n, 2, d_pts + 2 * b, d_ev + 4 * b);
+    if (rc) return rc;
+    ZK_LAUNCH(ctx, "fri_join_evals", fri_join_evals_kernel, dim3(1), dim3(64), 0, (const u64 *)d_ev, nb, d_y);
+    for (u32 par = 0; rc == ZK_OK && par < (1u << rate_bits); par++) {
+        u64 shift = gl_mul(GL_GEN, gl_pow(gl_root(lgL), par));
+        TwoLevel pre = zk_scale_table(ctx, shift, 1, log_n);
+        rc = zk_ntt_dit(ctx, P, n, Pval + (size_t)bitrev_u32(par, rate_bits) * n, L, log_n, 2 * nb, 0, &pre, nullptr, 1, tmp, n);
+    }
+    if (rc) return rc;
+    QuotGenParams qp = {};
+    qp.Pval = Pval; qp.L = L; qp.lgL = lgL; qp.nb = nb;
+    TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
+    qp.xA = xs.A; qp.xB = xs.B; qp.pts = d_pts; qp.y = d_y; qp.shifts = d_apow + 2 * gp.cnt; qp.F = F;
+    ZK_LAUNCH(ctx, "fri_quotient", fri_quotient_gen_kernel, g1(L), dim3(256), 0, qp);
+    ctx->release(d_alpha); ctx->release(d_apow); ctx->release(d_pts); ctx->release(d_ev); ctx->release(d_y); ctx->release((void *)d_cols);
+    ctx->release(P); ctx->release(Pval); ctx->release(tmp);
+    rc = zk_fri_proof_dev(ctx, cfg, ch, log_n, F, oracles, n_oracles, d_proof, lay);
+    ctx->release(F);
+    return rc;
 }

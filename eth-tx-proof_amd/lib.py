@@ -383,3 +383,20 @@ def fri_prove_openings(ctx, cfg, trace_batch, aux_batch, quot_batch, challenger,
                                          quot_batch.h, challenger.h, _p(z), _p(out), C.c_size_t(n), C.byref(ln)),
              "zk_fri_prove_openings")
     return out[:ln.value]
+
+
+def fri_prove_instance(ctx, cfg, oracles, batches, challenger):
+    """PolynomialBatch::prove_openings for any FriInstanceInfo: oracles = [Batch], batches = [(point_ext, [(oracle, poly)])]"""
+    from . import _abi
+    f = lib().zk_fri_instance_proof_size_words
+    f.restype = C.c_size_t
+    ncols = (C.c_uint32 * len(oracles))(*[o.n_cols for o in oracles])
+    n = f(C.byref(cfg), C.c_uint32(oracles[0].log_n), C.c_uint32(len(oracles)), ncols)
+    out = np.empty(n, dtype=np.uint64)
+    hs = (C.c_void_p * len(oracles))(*[o.h for o in oracles])
+    arr, keep = _abi.fri_instance(batches)
+    ln = C.c_size_t(0)
+    ctx._chk(lib().zk_fri_prove_instance(ctx.h, C.byref(cfg), C.c_uint32(len(oracles)), hs, C.c_uint32(len(batches)), arr,
+                                         challenger.h, _p(out), C.c_size_t(n), C.byref(ln)), "zk_fri_prove_instance")
+    del keep
+    return out[:ln.value]

@@ -236,6 +236,23 @@ int32_t zk_fri_prove_openings(zk_ctx *ctx, const zk_stark_config *cfg, zk_batch 
                               zk_challenger *ch, const uint64_t zeta[2], uint64_t *fri_proof_out, size_t cap_words,
                               size_t *len_words);
 
+/* plonky2::fri::structure::{FriPolynomialInfo, FriBatchInfo, FriInstanceInfo} and
+ * plonky2::fri::oracle::PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params) for ANY instance (the
+ * entry point the Plonk recursion proofs of SURVEY.md 8f-2 need: 4 oracles, rate_bits 3, batches at zeta and g*zeta):
+ * every batch opens the listed polynomials (oracle_index into `oracles`, polynomial_index into that oracle's columns) at
+ * `point` (an extension element).  All oracles share log_n and were committed with cfg->rate_bits / cfg->cap_height.
+ * n_oracles <= 8, n_batches <= 4, every batch non-empty.  Advances `ch` as upstream does (alpha, per-layer caps and betas,
+ * final polynomial, PoW witness, query indices) and writes the FriProof words: n_layers, caps, final_poly_len, final_poly,
+ * pow_witness, then per query round {per oracle: leaf row, Merkle path} {per layer: 2^arity_bits ext evals, path}.
+ * A base-field point that lies on the LDE coset g*H (where the pointwise quotient is undefined; upstream's synthetic
+ * division would still succeed there) is refused with ZK_ERR_ZETA_IN_SUBGROUP. */
+typedef struct zk_fri_poly { uint32_t oracle_index, polynomial_index; } zk_fri_poly;
+typedef struct zk_fri_batch { uint64_t point[2]; uint32_t n_polys; uint32_t reserved; const zk_fri_poly *polys; } zk_fri_batch;
+size_t zk_fri_instance_proof_size_words(const zk_stark_config *cfg, uint32_t log_n, uint32_t n_oracles, const uint32_t *oracle_n_cols);
+int32_t zk_fri_prove_instance(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_oracles, zk_batch *const *oracles,
+                              uint32_t n_batches, const zk_fri_batch *batches, zk_challenger *ch, uint64_t *fri_proof_out,
+                              size_t cap_words, size_t *len_words);
+
 /* Synthetic satisfying witness for eth_tx_proof_amd.air.cpu_like_air, generated in HBM;
  * public_inputs_out (host, 3 words, may be NULL) = first-row a0, b0 and last-row a0. */
 int32_t zk_synth_trace_dev(zk_ctx *ctx, uint32_t n_cols, uint32_t log_n, uint64_t seed, uint64_t *d_trace,

@@ -115,6 +115,8 @@ int32_t orc_quotient(const zk_stark_config *cfg, const zk_air *air, uint32_t log
 int32_t orc_pow_grind(const uint64_t state[12], uint32_t pos, uint32_t min_zeros, uint64_t *witness);
 int32_t orc_fri_prove(const zk_stark_config *cfg, const orc_batch *trace_b, const orc_batch *aux_b, const orc_batch *quot_b,
                       orc_challenger *ch, const uint64_t zeta[2], uint64_t *out, size_t cap_words, size_t *len_words);
+int32_t orc_fri_prove_instance(const zk_stark_config *cfg, uint32_t n_oracles, const orc_batch *const *oracles, uint32_t n_batches,
+                               const zk_fri_batch *batches, orc_challenger *ch, uint64_t *out, size_t cap_words, size_t *len_words);
 size_t orc_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const orc_table *tables);
 
 #ifdef __cplusplus

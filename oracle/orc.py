@@ -268,3 +268,26 @@ def fri_prove(cfg, trace_batch, aux_batch, quot_batch, challenger, zeta, cap_wor
     rc = lib().orc_fri_prove(C.byref(cfg), trace_batch.h, aux_batch.h if aux_batch is not None else None, quot_batch.h,
                              C.byref(challenger.s), _p(z), _p(out), C.c_size_t(cap_words), C.byref(ln))
     return rc, out[:ln.value]
+
+
+def fri_prove_instance(cfg, oracles, batches, challenger, cap_words=1 << 23):
+    """counterpart of zk_fri_prove_instance: oracles = [Batch], batches = [(point_ext, [(oracle, poly)])]"""
+    class FriPoly(C.Structure):
+        _fields_ = [("oracle_index", C.c_uint32), ("polynomial_index", C.c_uint32)]
+
+    class FriBatch(C.Structure):
+        _fields_ = [("point", C.c_uint64 * 2), ("n_polys", C.c_uint32), ("reserved", C.c_uint32), ("polys", C.POINTER(FriPoly))]
+    arr = (FriBatch * len(batches))()
+    keep = []
+    for i, (pt, polys) in enumerate(batches):
+        pa = (FriPoly * max(1, len(polys)))(*[FriPoly(int(o), int(k)) for o, k in polys])
+        keep.append(pa)
+        arr[i].point[0], arr[i].point[1] = int(pt[0]), int(pt[1])
+        arr[i].n_polys = len(polys)
+        arr[i].polys = C.cast(pa, C.POINTER(FriPoly))
+    hs = (C.c_void_p * len(oracles))(*[o.h for o in oracles])
+    out = np.empty(cap_words, dtype=np.uint64)
+    ln = C.c_size_t(0)
+    rc = lib().orc_fri_prove_instance(C.byref(cfg), C.c_uint32(len(oracles)), hs, C.c_uint32(len(batches)), arr,
+                                      C.byref(challenger.s), _p(out), C.c_size_t(cap_words), C.byref(ln))
+    return rc, out[:ln.value]

@@ -153,29 +153,26 @@ typedef struct {
     uint64_t *aux_vals;
 } tbl_state;
 
-/* PolynomialBatch::prove_openings + fri_proof for one table */
-static int32_t fri_prove(const zk_stark_config *cfg, tbl_state *T, orc_challenger *ch, gl2 zeta, wr *w) {
-    uint32_t log_n = T->in->log_n, lgL = log_n + cfg->rate_bits;
+/* plonky2::fri::structure::FriInstanceInfo restated: oracles + batches of (point, [(oracle, polynomial)]) */
+typedef struct {
+    uint32_t n_oracles; const orc_batch *const *oracles;
+    uint32_t n_batches; const gl2 *points; const uint32_t *cnt; const zk_fri_poly *const *polys;
+} fri_instance;
+
+/* PolynomialBatch::prove_openings + fri_proof */
+static int32_t fri_prove_instance(const zk_stark_config *cfg, const fri_instance *I, orc_challenger *ch, wr *w) {
+    uint32_t log_n = I->oracles[0]->log_n, lgL = log_n + cfg->rate_bits;
     size_t n = (size_t)1 << log_n, L = (size_t)1 << lgL;
-    uint32_t C = T->in->air->n_trace_cols, A = T->n_aux, Q = T->quot_b->n_cols, nch = cfg->num_challenges;
     uint64_t ab[2]; orc_challenger_get_n(ch, 2, ab);
     gl2 alpha = {ab[0], ab[1]};
-    uint64_t g_n = gl_root(log_n);
-    /* batches: (zeta: trace|aux|quot) (g*zeta: trace|aux) (1: ctl Zs) */
-    gl2 points[3] = {zeta, gl2_scale(zeta, g_n), {1, 0}};
-    uint32_t nb = A ? 3 : 2;
+    uint32_t nb = I->n_batches;
     gl2 *final_poly = (gl2 *)calloc(L, sizeof(gl2));
     gl2 *comp = (gl2 *)malloc(n * sizeof(gl2));
     for (uint32_t b = 0; b < nb; b++) {
         /* list the polynomials of this batch */
-        uint32_t cnt = b == 0 ? C + A + Q : b == 1 ? C + A : nch;
-        const uint64_t **polys = (const uint64_t **)malloc(cnt * sizeof(uint64_t *));
-        uint32_t k = 0;
-        if (b < 2) {
-            for (uint32_t c = 0; c < C; c++) polys[k++] = T->trace_b->coeffs + (size_t)c * n;
-            for (uint32_t c = 0; c < A; c++) polys[k++] = T->aux_b->coeffs + (size_t)c * n;
-            if (b == 0) for (uint32_t c = 0; c < Q; c++) polys[k++] = T->quot_b->coeffs + (size_t)c * n;
-        } else for (uint32_t j = 0; j < nch; j++) polys[k++] = T->aux_b->coeffs + (size_t)(A - nch + j) * n;
+        uint32_t cnt = I->cnt[b];
+        const uint64_t **polys = (const uint64_t **)malloc((cnt ? cnt : 1) * sizeof(uint64_t *));
+        for (uint32_t k = 0; k < cnt; k++) polys[k] = I->oracles[I->polys[b][k].oracle_index]->coeffs + (size_t)I->polys[b][k].polynomial_index * n;
         /* ReducingFactor::reduce_polys_base: sum_j alpha^j f_j (Horner from the last polynomial) */
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; i++) {
@@ -185,7 +182,7 @@ static int32_t fri_prove(const zk_stark_config *cfg, tbl_state *T, orc_challenge
         }
         free(polys);
         /* divide_by_linear(point): Horner scan from the top coefficient, drop the remainder, push a zero */
-        gl2 z = points[b], acc = {0, 0};
+        gl2 z = I->points[b], acc = {0, 0};
         gl2 *q = (gl2 *)malloc(n * sizeof(gl2));
         for (size_t i = n; i-- > 0;) { acc = gl2_add(gl2_mul(acc, z), comp[i]); if (i > 0) q[i - 1] = acc; }
         q[n - 1].a = 0; q[n - 1].b = 0;
@@ -268,8 +265,7 @@ static int32_t fri_prove(const zk_stark_config *cfg, tbl_state *T, orc_challenge
     uint32_t nq = cfg->num_query_rounds;
     uint64_t *qs = (uint64_t *)malloc(nq * sizeof(uint64_t));
     orc_challenger_get_n(ch, nq, qs);
-    orc_batch *oracles[3]; uint32_t no = 0;
-    oracles[no++] = T->trace_b; if (A) oracles[no++] = T->aux_b; oracles[no++] = T->quot_b;
+    const orc_batch *const *oracles = I->oracles; uint32_t no = I->n_oracles;
     uint32_t npath = lgL - cfg->cap_height;
     uint64_t *sib = (uint64_t *)malloc((size_t)(npath + 1) * 4 * sizeof(uint64_t));
     for (uint32_t q = 0; q < nq; q++) {
@@ -294,6 +290,29 @@ static int32_t fri_prove(const zk_stark_config *cfg, tbl_state *T, orc_challenge
     for (uint32_t l = 0; l < nl; l++) { free(layer_leaves[l]); orc_tree_free(layer_tree[l]); }
     free(layer_leaves); free(layer_tree); free(values); free(final_poly);
     return ZK_OK;
+}
+
+/* the STARK instance of one table: batches (zeta: trace|aux|quot) (g*zeta: trace|aux) (1: ctl Zs) over oracles trace[, aux], quot */
+static int32_t fri_prove(const zk_stark_config *cfg, tbl_state *T, orc_challenger *ch, gl2 zeta, wr *w) {
+    uint32_t log_n = T->in->log_n, nch = cfg->num_challenges;
+    uint32_t C = T->in->air->n_trace_cols, A = T->n_aux, Q = T->quot_b->n_cols;
+    const orc_batch *oracles[3]; uint32_t no = 0, o_aux = 0, o_q;
+    oracles[no++] = T->trace_b; if (A) { o_aux = no; oracles[no++] = T->aux_b; } o_q = no; oracles[no++] = T->quot_b;
+    gl2 points[3] = {zeta, gl2_scale(zeta, gl_root(log_n)), {1, 0}};
+    uint32_t cnt[3] = {C + A + Q, C + A, nch};
+    zk_fri_poly *pl[3];
+    for (uint32_t b = 0; b < 3; b++) pl[b] = (zk_fri_poly *)malloc((cnt[b] ? cnt[b] : 1) * sizeof(zk_fri_poly));
+    for (uint32_t b = 0; b < 2; b++) {
+        uint32_t k = 0;
+        for (uint32_t c = 0; c < C; c++) pl[b][k++] = (zk_fri_poly){0, c};
+        for (uint32_t c = 0; c < A; c++) pl[b][k++] = (zk_fri_poly){o_aux, c};
+        if (b == 0) for (uint32_t c = 0; c < Q; c++) pl[b][k++] = (zk_fri_poly){o_q, c};
+    }
+    if (A) for (uint32_t j = 0; j < nch; j++) pl[2][j] = (zk_fri_poly){o_aux, A - nch + j};
+    fri_instance I = {no, oracles, A ? 3u : 2u, points, cnt, (const zk_fri_poly *const *)pl};
+    int32_t rc = fri_prove_instance(cfg, &I, ch, w);
+    for (uint32_t b = 0; b < 3; b++) free(pl[b]);
+    return rc;
 }
 
 /* starky::prover::compute_quotient_polys (A9/A7 step 4) -> 2*num_challenges coefficient polys of length n */
@@ -477,6 +496,25 @@ int32_t orc_fri_prove(const zk_stark_config *cfg, const orc_batch *trace_b, cons
     wr w = {out, cap_words, 0, 0};
     gl2 z = {gl_canon(zeta[0]), gl_canon(zeta[1])};
     int32_t rc = fri_prove(cfg, &T, ch, z, &w);
+    if (len_words) *len_words = w.len;
+    if (rc) return rc;
+    return w.overflow ? ZK_ERR_BUFFER_TOO_SMALL : ZK_OK;
+}
+/* PolynomialBatch::prove_openings for any FriInstanceInfo (counterpart of zk_fri_prove_instance) */
+int32_t orc_fri_prove_instance(const zk_stark_config *cfg, uint32_t n_oracles, const orc_batch *const *oracles, uint32_t n_batches,
+                               const zk_fri_batch *batches, orc_challenger *ch, uint64_t *out, size_t cap_words, size_t *len_words) {
+    if (!n_oracles || n_oracles > 8 || !n_batches || n_batches > 4) return ZK_ERR_INVALID_ARG;
+    gl2 points[4]; uint32_t cnt[4]; const zk_fri_poly *pl[4];
+    for (uint32_t b = 0; b < n_batches; b++) {
+        points[b] = (gl2){gl_canon(batches[b].point[0]), gl_canon(batches[b].point[1])};
+        cnt[b] = batches[b].n_polys; pl[b] = batches[b].polys;
+        for (uint32_t k = 0; k < cnt[b]; k++)
+            if (pl[b][k].oracle_index >= n_oracles || pl[b][k].polynomial_index >= oracles[pl[b][k].oracle_index]->n_cols) return ZK_ERR_INVALID_ARG;
+    }
+    for (uint32_t o = 1; o < n_oracles; o++) if (oracles[o]->log_n != oracles[0]->log_n) return ZK_ERR_INVALID_ARG;
+    fri_instance I = {n_oracles, oracles, n_batches, points, cnt, pl};
+    wr w = {out, cap_words, 0, 0};
+    int32_t rc = fri_prove_instance(cfg, &I, ch, &w);
     if (len_words) *len_words = w.len;
     if (rc) return rc;
     return w.overflow ? ZK_ERR_BUFFER_TOO_SMALL : ZK_OK;

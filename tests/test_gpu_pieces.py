@@ -85,3 +85,103 @@ def test_fri_prove_openings(ctx, zk, orc, n_helpers, log_n):
     rc, ref = orc.fri_prove(cfg, ob, oab, oqb, och, zeta)
     assert rc == 0 and got.size == ref.size and (got == ref).all()
     assert (gch.get(3) == och.get(3)).all()
+
+
+def _stark_instance(n_cols, n_aux, n_q, nch, zeta, log_n):
+    """the FriInstanceInfo a starky table has: (zeta: trace|aux|quot) (g*zeta: trace|aux) (1: ctl Zs)"""
+    import pyspec
+    P = 0xFFFFFFFF00000001
+    g = pyspec.root_of_unity(log_n)
+    o_q = 2 if n_aux else 1
+    b0 = [(0, c) for c in range(n_cols)] + [(1, c) for c in range(n_aux)] + [(o_q, c) for c in range(n_q)]
+    b1 = [(0, c) for c in range(n_cols)] + [(1, c) for c in range(n_aux)]
+    out = [(zeta, b0), ((int(zeta[0]) * g % P, int(zeta[1]) * g % P), b1)]
+    if n_aux:
+        out.append(((1, 0), [(1, n_aux - nch + j) for j in range(nch)]))
+    return out
+
+
+@pytest.mark.parametrize("n_helpers,log_n", [(2, 8), (0, 7)])
+def test_fri_instance_equals_stark_entry(ctx, zk, orc, n_helpers, log_n):
+    """zk_fri_prove_instance on the instance a STARK table has == zk_fri_prove_openings == the oracle's generic restatement"""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    rng = np.random.default_rng(40 + log_n)
+    prog = air.cpu_like_air(9, n_helpers)
+    tr, pub = orc.synth_trace(9, log_n, 5)
+    ch4, al = field_rand(rng, 4), field_rand(rng, 2)
+    tb, ob = ctx.batch_from_values(tr), orc.Batch(tr)
+    ab = oab = None
+    if n_helpers:
+        rc, aux = orc.aux_columns(prog, ch4, tr)
+        ab, oab = ctx.batch_from_values(aux), orc.Batch(aux)
+    q = orc.quotient(cfg, prog, ob, oab, pub, ch4, al)
+    qb, oqb = ctx.batch_from_coeffs(q), orc.Batch(q, from_coeffs=True)
+    zeta = field_rand(rng, 2)
+    inst = _stark_instance(9, prog.n_aux_cols if n_helpers else 0, q.shape[0], 2, zeta, log_n)
+    seed = field_rand(rng, 5)
+    outs = []
+    for which in range(3):
+        if which < 2:
+            c = ctx.challenger(); c.observe(seed)
+            gor = [b for b in (tb, ab, qb) if b is not None]
+            outs.append(zk.fri_prove_instance(ctx, cfg, gor, inst, c) if which == 0 else zk.fri_prove_openings(ctx, cfg, tb, ab, qb, c, zeta))
+        else:
+            c = orc.Challenger(); c.observe(seed)
+            rc, ref = orc.fri_prove_instance(cfg, [b for b in (ob, oab, oqb) if b is not None], inst, c)
+            assert rc == 0
+            outs.append(ref)
+    assert outs[0].size == outs[1].size == outs[2].size
+    assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+
+
+@pytest.mark.parametrize("log_n,widths", [(6, (5, 9, 4, 8)), (9, (20, 135, 20, 16)), (12, (4, 135, 20, 16))])
+def test_fri_instance_recursion_shape(ctx, zk, orc, log_n, widths):
+    """the shape of a plonky2 recursion proof's opening: four oracles (constants+sigmas, wires, Zs+partial
+    products, quotient chunks) committed at rate_bits 3, everything opened at zeta, the Z polynomials also at g*zeta;
+    standard_recursion_config FRI (28 queries, arity 16, PoW 16).  Bit-exact against the oracle, same challenger after."""
+    import eth_tx_proof_amd as E
+    import pyspec
+    P = 0xFFFFFFFF00000001
+    cfg = E.standard_recursion_config()
+    rng = np.random.default_rng(log_n)
+    gb, ob = [], []
+    for k, w in enumerate(widths):
+        v = field_rand(rng, (w, 1 << log_n))
+        if k == 3:
+            gb.append(ctx.batch_from_coeffs(v, rate_bits=3, cap_height=4)); ob.append(orc.Batch(v, rate_bits=3, cap_height=4, from_coeffs=True))
+        else:
+            gb.append(ctx.batch_from_values(v, rate_bits=3, cap_height=4)); ob.append(orc.Batch(v, rate_bits=3, cap_height=4))
+        assert (gb[-1].cap == ob[-1].cap).all()
+    zeta = field_rand(rng, 2)
+    g = pyspec.root_of_unity(log_n)
+    inst = [(zeta, [(o, c) for o, w in enumerate(widths) for c in range(w)]),
+            ((int(zeta[0]) * g % P, int(zeta[1]) * g % P), [(2, c) for c in range(2)])]
+    seed = field_rand(rng, 7)
+    gch, och = ctx.challenger(), orc.Challenger()
+    gch.observe(seed); och.observe(seed)
+    got = zk.fri_prove_instance(ctx, cfg, gb, inst, gch)
+    rc, ref = orc.fri_prove_instance(cfg, ob, inst, och)
+    assert rc == 0 and got.size == ref.size and (got == ref).all()
+    assert (gch.get(4) == och.get(4)).all()
+    for b in gb:
+        b.free()
+
+
+def test_fri_instance_error_paths(ctx, zk):
+    import eth_tx_proof_amd as E
+    cfg = E.standard_fast_config()
+    rng = np.random.default_rng(1)
+    b = ctx.batch_from_values(field_rand(rng, (3, 64)))
+    c = ctx.challenger()
+    with pytest.raises(zk.ZkError) as e:      # polynomial index out of range
+        zk.fri_prove_instance(ctx, cfg, [b], [((5, 6), [(0, 3)])], c)
+    assert e.value.code == -1
+    with pytest.raises(zk.ZkError) as e:      # empty batch
+        zk.fri_prove_instance(ctx, cfg, [b], [((5, 6), [])], c)
+    assert e.value.code == -1
+    with pytest.raises(zk.ZkError) as e:      # base-field point on the LDE coset g*H
+        zk.fri_prove_instance(ctx, cfg, [b], [((E.COSET_SHIFT, 0), [(0, 0)])], c)
+    assert e.value.code == -8
+    # a valid call still works afterwards
+    assert zk.fri_prove_instance(ctx, cfg, [b], [((5, 6), [(0, 0), (0, 2)])], c).size > 0

@@ -108,6 +108,24 @@ def test_batch_from_values(ctx, orc, log_n, ncols, cap_h):
     b.free()
 
 
+@pytest.mark.parametrize("log_n,ncols,rate_bits,cap_h", [(5, 3, 0, 2), (6, 5, 2, 4), (8, 135, 3, 4), (12, 9, 3, 4), (3, 2, 4, 0), (4, 4, 3, 4)])
+def test_batch_rate_bits(ctx, orc, log_n, ncols, rate_bits, cap_h):
+    """blow-ups other than the STARK config's 2: 1 (no LDE), 4, 8 (standard_recursion_config), 16"""
+    rng = np.random.default_rng(log_n * 10 + rate_bits)
+    vals = field_rand(rng, (ncols, 1 << log_n))
+    b = ctx.batch_from_values(vals, rate_bits=rate_bits, cap_height=cap_h)
+    o = orc.Batch(vals, rate_bits=rate_bits, cap_height=cap_h)
+    assert (b.cap == o.cap).all()
+    assert (b.digests() == o.digests).all()
+    L = 1 << (log_n + rate_bits)
+    for leaf in (0, 1, L // 2, L - 1):
+        assert (b.leaf(leaf) == o.leaves[leaf]).all()
+        assert (b.prove(leaf) == o.prove(leaf)).all()
+    z = field_rand(rng, 2)
+    assert (b.eval_at(z) == o.eval_at(z)).all()
+    b.free()
+
+
 @pytest.mark.parametrize("log_n,ncols", [(4, 4), (8, 4), (12, 4), (10, 7)])
 def test_batch_from_coeffs(ctx, orc, log_n, ncols):
     rng = np.random.default_rng(log_n + ncols)
