@@ -1,6 +1,7 @@
 // Context, stream-ordered caching allocator, per-kernel hipEvent profiler, device-memory helpers.
 // Boundary: include/zkgl.h "context" group.  One ctx = one device + one HIP stream = one worker thread of the
 // reference's runtime (paladin `--num-workers N`, /root/reference/README.md:60-63).
+#include <stdlib.h>
 #include "zk_internal.h"
 
 void *zk_ctx::alloc(size_t bytes) {
@@ -79,6 +80,7 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return ZK_ERR_HIP;
     zk_ctx *c = new zk_ctx();
     c->device = device;
+    { const char *e = getenv("ZK_FORCE_EXACT_REDO"); c->force_redo = (e && atoi(e)) ? 1 : 0; }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZK_ERR_HIP; }

@@ -36,12 +36,6 @@ __device__ __forceinline__ u64 wred128(u64 lo, u64 hi) {
     return r2;
 }
 __device__ __forceinline__ u64 wmul(u64 a, u64 b) { u64 lo, hi; mul128(a, b, lo, hi); return wred128(lo, hi); }
-// a*b + c for any 64-bit a, b, c (cannot overflow 128 bits)
-__device__ __forceinline__ u64 wmul_add(u64 a, u64 b, u64 c) {
-    u64 lo, hi; mul128(a, b, lo, hi);
-    u64 l2 = lo + c; hi += (l2 < lo);
-    return wred128(l2, hi);
-}
 // weak a + canonical c: the sum is below 2^64 + p, so one eps repair suffices
 __device__ __forceinline__ u64 wadd_c(u64 a, u64 c) {
     u64 s; bool cy = __builtin_add_overflow(a, c, &s);
@@ -101,92 +95,128 @@ struct acc3 {
               [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
             : [a0] "s"(a0), [a1] "s"(a1), [b0] "v"(b0), [b1] "v"(b1));
     }
-    // value = c0 + c1*2^32 + c2*2^64 + o0*2^64 + o1*2^96 + o2*2^128;  2^64 = eps, 2^96 = -1, 2^128 = -2^32.  Weak result.
-    __device__ __forceinline__ u64 reduce() const {
-        u64 L; bool cL = __builtin_add_overflow(c0, c1 << 32, &L);
-        u64 H1 = c2 + (c1 >> 32);
-        bool w1 = H1 < c2;
+};
+
+// The permutation proper.  Every reduction ends in "r - h" with h a 32-bit value and r freshly reduced, so the subtraction
+// borrows only when r < 2^32: about one lane in 2^32.  The straight-line compare + select repair of that borrow was 4 of the
+// ~19 VALU instructions of every product.  core<false> skips it: the borrow mask that v_subbrev_co_u32 delivers anyway is
+// OR-ed into a wave-uniform sticky word `fl` with one SALU instruction, and the kernel that ran the fast path re-runs the
+// same input through core<true> (all repairs in place) when fl != 0 -- results are identical either way, bit for bit.
+template <bool EXACT> struct core {
+    u64 fl;
+    __device__ __forceinline__ u64 sub32(u64 r, u32 h) {
+        if (EXACT) {
+            u64 d; bool b = __builtin_sub_overflow(r, (u64)h, &d);
+            return d - (b ? GL_EPS : 0ull);
+        } else {
+            u32 rl = (u32)r, rh = (u32)(r >> 32), dl, dh; u64 k;
+            asm("v_sub_co_u32 %[dl], %[k], %[rl], %[h]\n\t"
+                "s_nop 1\n\t"
+                "v_subbrev_co_u32 %[dh], %[k], 0, %[rh], %[k]\n\t"
+                : [dl] "=&v"(dl), [dh] "=&v"(dh), [k] "=&s"(k)
+                : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h));
+            fl |= k;
+            return ((u64)dh << 32) | dl;
+        }
+    }
+    __device__ __forceinline__ u64 red128(u64 lo, u64 hi) { return sub32(gl_mad_eps((u32)hi, lo), (u32)(hi >> 32)); }
+    __device__ __forceinline__ u64 mul(u64 a, u64 b) { u64 lo, hi; mul128(a, b, lo, hi); return red128(lo, hi); }
+    // a*b + c for any 64-bit a, b, c (cannot overflow 128 bits)
+    __device__ __forceinline__ u64 mul_add(u64 a, u64 b, u64 c) {
+        u64 lo, hi; mul128(a, b, lo, hi);
+        u64 l2 = lo + c; hi += (l2 < lo);
+        return red128(l2, hi);
+    }
+    __device__ __forceinline__ u64 sbox(u64 x) {
+        u64 x2 = mul(x, x), x3 = mul(x2, x), x4 = mul(x2, x2);
+        return mul(x3, x4);
+    }
+    // acc3 value = c0 + c1*2^32 + c2*2^64 + o0*2^64 + o1*2^96 + o2*2^128;  2^64 = eps, 2^96 = -1, 2^128 = -2^32.  Weak result.
+    __device__ __forceinline__ u64 reduce(const acc3 &a) {
+        u64 L; bool cL = __builtin_add_overflow(a.c0, a.c1 << 32, &L);
+        u64 H1 = a.c2 + (a.c1 >> 32);
+        bool w1 = H1 < a.c2;
         u64 H = H1 + (cL ? 1 : 0);
         bool w2 = H < H1;
-        u32 top = o2 + (w1 ? 1 : 0) + (w2 ? 1 : 0);
-        u64 r = wred128(L, H);
-        u64 t = (u64)o0 * 0xFFFFFFFFu;
-        u64 r1; bool cy = __builtin_add_overflow(r, t, &r1);
-        r1 += cy ? GL_EPS : 0ull;
-        u64 sub = (u64)o1 + ((u64)top << 32);
+        u32 top = a.o2 + (w1 ? 1 : 0) + (w2 ? 1 : 0);
+        u64 r = red128(L, H);
+        u64 r1 = gl_mad_eps(a.o0, r);
+        u64 sub = (u64)a.o1 + ((u64)top << 32);      // can exceed 32 bits: keep the straight-line repair here (22 per permutation)
         u64 r2; bool b = __builtin_sub_overflow(r1, sub, &r2);
         return r2 - (b ? GL_EPS : 0ull);
     }
+// out[r] = sum_i s[(i+r)%12]*CIRC[i] + (r==0)*8*s[0],  CIRC = [17,15,41,16,2,28,13,13,39,18,34,20]; weak in, weak out
+    __device__ __forceinline__ void mds_layer(u64 s[12]) {
+        const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+        u32 lo[12], hi[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+#pragma unroll
+        for (int r = 0; r < 12; r++) {
+            u64 al = 0, ah = 0;
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                al += (u64)lo[(i + r) % 12] * C[i];
+                ah += (u64)hi[(i + r) % 12] * C[i];
+            }
+            if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
+            // value = al + ah*2^32 with al, ah < 2^42:  low64 + high*2^64, high < 2^11  ->  low + high*eps, one eps repair
+            u64 low = al + (ah << 32);
+            u64 high = (ah >> 32) + (low < al);
+            s[r] = gl_mad_eps((u32)high, low);
+        }
+    }
+
+    __device__ __forceinline__ void full_rounds(u64 s[12], int first_round) {
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) {
+            const u64 *rc = PSD_RC + 12 * (first_round + r);
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = sbox(wadd_c(s[i], rc[i]));
+            mds_layer(s);
+        }
+    }
+
+    __device__ __forceinline__ void partial_rounds(u64 s[12]) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = wadd_c(s[i], PSD_PR_FIRST[i]);
+        {   // s[1..] = PR_INIT * s[1..]
+            u64 t[11];
+#pragma unroll
+            for (int i = 0; i < 11; i++) {
+                acc3 a; a.init();
+#pragma unroll
+                for (int j = 0; j < 11; j++) a.mac_s(PSD_PR_INIT[11 * i + j], s[1 + j]);
+                t[i] = reduce(a);
+            }
+#pragma unroll
+            for (int i = 0; i < 11; i++) s[1 + i] = t[i];
+        }
+#pragma unroll 1
+        for (int r = 0; r < 22; r++) {
+            u64 s0 = wadd_c(sbox(s[0]), PSD_PR_K[r]);
+            acc3 a; a.init();
+            a.c0 = (u64)(u32)s0 * (u32)PSD_M00; a.c1 = (s0 >> 32) * (u32)PSD_M00;      // 25 * s0 in the first two columns
+            const u64 *vh = PSD_PR_VHAT + 11 * r, *w = PSD_PR_W + 11 * r;
+#pragma unroll
+            for (int j = 0; j < 11; j++) a.mac_s(vh[j], s[1 + j]);
+#pragma unroll
+            for (int j = 0; j < 11; j++) s[1 + j] = mul_add(w[j], s0, s[1 + j]);
+            s[0] = reduce(a);
+        }
+    }
+
+    // any 64-bit representatives in; canonical out
+    __device__ __forceinline__ void run(u64 s[12]) {
+        full_rounds(s, 0);
+        partial_rounds(s);
+        full_rounds(s, 26);
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+    }
 };
 
-// out[r] = sum_i s[(i+r)%12]*CIRC[i] + (r==0)*8*s[0],  CIRC = [17,15,41,16,2,28,13,13,39,18,34,20]; weak in, weak out
-__device__ __forceinline__ void mds_layer(u64 s[12]) {
-    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    u32 lo[12], hi[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
-#pragma unroll
-    for (int r = 0; r < 12; r++) {
-        u64 al = 0, ah = 0;
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            al += (u64)lo[(i + r) % 12] * C[i];
-            ah += (u64)hi[(i + r) % 12] * C[i];
-        }
-        if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
-        // value = al + ah*2^32 with al, ah < 2^42:  low64 + high*2^64, high < 2^11  ->  low + high*eps, one eps repair
-        u64 low = al + (ah << 32);
-        u64 high = (ah >> 32) + (low < al);
-        s[r] = gl_mad_eps((u32)high, low);
-    }
-}
-
-__device__ __forceinline__ void full_rounds(u64 s[12], int first_round) {
-#pragma unroll 1
-    for (int r = 0; r < 4; r++) {
-        const u64 *rc = PSD_RC + 12 * (first_round + r);
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = wsbox7(wadd_c(s[i], rc[i]));
-        mds_layer(s);
-    }
-}
-
-__device__ __forceinline__ void partial_rounds(u64 s[12]) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = wadd_c(s[i], PSD_PR_FIRST[i]);
-    {   // s[1..] = PR_INIT * s[1..]
-        u64 t[11];
-#pragma unroll
-        for (int i = 0; i < 11; i++) {
-            acc3 a; a.init();
-#pragma unroll
-            for (int j = 0; j < 11; j++) a.mac_s(PSD_PR_INIT[11 * i + j], s[1 + j]);
-            t[i] = a.reduce();
-        }
-#pragma unroll
-        for (int i = 0; i < 11; i++) s[1 + i] = t[i];
-    }
-#pragma unroll 1
-    for (int r = 0; r < 22; r++) {
-        u64 s0 = wadd_c(wsbox7(s[0]), PSD_PR_K[r]);
-        acc3 a; a.init();
-        a.c0 = (u64)(u32)s0 * (u32)PSD_M00; a.c1 = (s0 >> 32) * (u32)PSD_M00;      // 25 * s0 in the first two columns
-        const u64 *vh = PSD_PR_VHAT + 11 * r, *w = PSD_PR_W + 11 * r;
-#pragma unroll
-        for (int j = 0; j < 11; j++) a.mac_s(vh[j], s[1 + j]);
-#pragma unroll
-        for (int j = 0; j < 11; j++) s[1 + j] = wmul_add(w[j], s0, s[1 + j]);
-        s[0] = a.reduce();
-    }
-}
-
-// any 64-bit representatives in; canonical out
-__device__ __forceinline__ void permute(u64 s[12]) {
-    full_rounds(s, 0);
-    partial_rounds(s);
-    full_rounds(s, 26);
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
-}
+// any 64-bit representatives in; canonical out.  All repairs in place: for callers that are not hot.
+__device__ __forceinline__ void permute(u64 s[12]) { core<true> c; c.fl = 0; c.run(s); }
 
 }  // namespace psd

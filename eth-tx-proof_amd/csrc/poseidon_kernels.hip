@@ -8,65 +8,89 @@
 #include "zk_internal.h"
 #include "poseidon_coop.cuh"
 
+// sponge over the columns of one leaf; returns the sticky word of psd::core<false> (0 for EXACT)
+template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_colmajor(const u64 *__restrict__ p, size_t stride, u32 n_cols, u64 s[12]) {
+    psd::core<EXACT> pc; pc.fl = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    u32 c = 0;
+    for (; c + 8 <= n_cols; c += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = p[(size_t)(c + k) * stride];
+        pc.run(s);
+    }
+    if (c < n_cols) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (c + k < n_cols) s[k] = p[(size_t)(c + k) * stride];
+        pc.run(s);
+    }
+    return pc.fl;
+}
 // leaf i = (cols[c*stride + i])_{c < n_cols};  digest -> out[4*i .. 4*i+3]
 __global__ __launch_bounds__(256) void hash_leaves_colmajor_kernel(const u64 *__restrict__ cols, size_t stride, u32 n_cols,
-                                                                   size_t n_leaves, u64 *__restrict__ out) {
+                                                                   size_t n_leaves, u64 *__restrict__ out, u64 force_redo) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
     u64 s[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = 0;
     if (n_cols <= 4) {            // hash_or_noop: short leaves are copied, zero padded
+#pragma unroll
+        for (int k = 0; k < 12; k++) s[k] = 0;
         for (u32 c = 0; c < n_cols; c++) s[c] = cols[(size_t)c * stride + i];
-    } else {
-        const u64 *p = cols + i;
-        u32 c = 0;
-        for (; c + 8 <= n_cols; c += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) s[k] = p[(size_t)(c + k) * stride];
-            psd::permute(s);
-        }
-        if (c < n_cols) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) if (c + k < n_cols) s[k] = p[(size_t)(c + k) * stride];
-            psd::permute(s);
-        }
+    } else if (leaf_sponge_colmajor<false>(cols + i, stride, n_cols, s) | force_redo) {
+        leaf_sponge_colmajor<true>(cols + i, stride, n_cols, s);      // a skipped rare repair somewhere in this wave: redo exactly
     }
     ulonglong2 *o = (ulonglong2 *)(out + 4 * i);
     o[0] = make_ulonglong2(s[0], s[1]);
     o[1] = make_ulonglong2(s[2], s[3]);
 }
 
+template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_rowmajor(const u64 *__restrict__ p, u32 leaf_len, int canon, u64 s[12]) {
+    psd::core<EXACT> pc; pc.fl = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = 0;
+    for (u32 c = 0; c < leaf_len; c += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (c + k < leaf_len) s[k] = canon ? gl_canon(p[c + k]) : p[c + k];
+        pc.run(s);
+    }
+    return pc.fl;
+}
 // leaf i = rows[i*leaf_len .. (i+1)*leaf_len)
 __global__ __launch_bounds__(256) void hash_leaves_rowmajor_kernel(const u64 *__restrict__ rows, u32 leaf_len, size_t n_leaves,
-                                                                   u64 *__restrict__ out, int canon) {
+                                                                   u64 *__restrict__ out, int canon, u64 force_redo) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
     const u64 *p = rows + i * (size_t)leaf_len;
     u64 s[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = 0;
     if (leaf_len <= 4) {
-        for (u32 c = 0; c < leaf_len; c++) s[c] = canon ? gl_canon(p[c]) : p[c];
-    } else {
-        for (u32 c = 0; c < leaf_len; c += 8) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) if (c + k < leaf_len) s[k] = canon ? gl_canon(p[c + k]) : p[c + k];
-            psd::permute(s);
-        }
+        for (int k = 0; k < 12; k++) s[k] = 0;
+        for (u32 c = 0; c < leaf_len; c++) s[c] = canon ? gl_canon(p[c]) : p[c];
+    } else if (leaf_sponge_rowmajor<false>(p, leaf_len, canon, s) | force_redo) {
+        leaf_sponge_rowmajor<true>(p, leaf_len, canon, s);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) out[4 * i + k] = s[k];
 }
 
 // parent j = two_to_one(child 2j, child 2j+1) = permute(L | R | 0^4)[0..4]
-__global__ __launch_bounds__(256) void merkle_level_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parents) {
-    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_parents) return;
+__device__ __forceinline__ void load_children(const u64 *__restrict__ child, size_t j, u64 s[12]) {
     const ulonglong2 *c = (const ulonglong2 *)(child + 8 * j);
     ulonglong2 a = c[0], b = c[1], d = c[2], e = c[3];
-    u64 s[12] = {a.x, a.y, b.x, b.y, d.x, d.y, e.x, e.y, 0, 0, 0, 0};
-    psd::permute(s);
+    s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = d.x; s[5] = d.y; s[6] = e.x; s[7] = e.y;
+    s[8] = s[9] = s[10] = s[11] = 0;
+}
+__global__ __launch_bounds__(256, 4) void merkle_level_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parents, u64 force_redo) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_parents) return;
+    u64 s[12];
+    load_children(child, j, s);
+    psd::core<false> pc; pc.fl = 0;
+    pc.run(s);
+    if (pc.fl | force_redo) {      // a skipped rare repair somewhere in this wave: redo exactly (poseidon.cuh)
+        load_children(child, j, s);
+        psd::permute(s);
+    }
     ulonglong2 *o = (ulonglong2 *)(parent + 4 * j);
     o[0] = make_ulonglong2(s[0], s[1]);
     o[1] = make_ulonglong2(s[2], s[3]);
@@ -137,11 +161,11 @@ __global__ void digests_layout_kernel(const u64 *levels, size_t n_leaves, u32 n_
 static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uint32_t n_cols, size_t n_leaves, u64 *digests) {
-    ZK_LAUNCH(ctx, "poseidon_leaf_hash", hash_leaves_colmajor_kernel, grid1(n_leaves), dim3(256), 0, cols, stride, n_cols, n_leaves, digests);
+    ZK_LAUNCH(ctx, "poseidon_leaf_hash", hash_leaves_colmajor_kernel, grid1(n_leaves), dim3(256), 0, cols, stride, n_cols, n_leaves, digests, ctx->force_redo);
     return ZK_OK;
 }
 int32_t zk_hash_leaves_rowmajor(zk_ctx *ctx, const u64 *rows, uint32_t leaf_len, size_t n_leaves, u64 *digests) {
-    ZK_LAUNCH(ctx, "poseidon_leaf_hash_rows", hash_leaves_rowmajor_kernel, grid1(n_leaves), dim3(256), 0, rows, leaf_len, n_leaves, digests, 1);
+    ZK_LAUNCH(ctx, "poseidon_leaf_hash_rows", hash_leaves_rowmajor_kernel, grid1(n_leaves), dim3(256), 0, rows, leaf_len, n_leaves, digests, 1, ctx->force_redo);
     return ZK_OK;
 }
 int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap_height) {
@@ -152,7 +176,7 @@ int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap
         if (cnt / 2 <= 16384)
             ZK_LAUNCH(ctx, "poseidon_merkle_level_coop", merkle_level_coop_kernel, grid1(cnt / 2 * 16), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
         else
-            ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_kernel, grid1(cnt / 2), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
+            ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_kernel, grid1(cnt / 2), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo);
         cur = nxt; cnt >>= 1;
     }
     return ZK_OK;

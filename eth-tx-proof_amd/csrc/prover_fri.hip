@@ -152,19 +152,24 @@ __global__ __launch_bounds__(256) void fri_quotient_kernel(QuotParams p) {
 }
 
 // leaves of a commit-phase layer: `arity` consecutive extension values, flattened [a0,b0,a1,b1,...]
-__global__ __launch_bounds__(256) void fri_leaf_hash_kernel(const u64 *__restrict__ re, const u64 *__restrict__ im, size_t n_leaves, u32 arity,
-                                                            u64 *__restrict__ out) {
-    size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (l >= n_leaves) return;
-    u64 s[12];
+template <bool EXACT> __device__ __forceinline__ u64 fri_leaf_sponge(const u64 *__restrict__ r, const u64 *__restrict__ m, u32 arity, u64 s[12]) {
+    psd::core<EXACT> pc; pc.fl = 0;
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = 0;
-    const u64 *r = re + l * arity, *m = im + l * arity;
     for (u32 c = 0; c < arity; c += 4) {
 #pragma unroll
         for (int k = 0; k < 4; k++) { s[2 * k] = r[c + k]; s[2 * k + 1] = m[c + k]; }
-        psd::permute(s);
+        pc.run(s);
     }
+    return pc.fl;
+}
+__global__ __launch_bounds__(256) void fri_leaf_hash_kernel(const u64 *__restrict__ re, const u64 *__restrict__ im, size_t n_leaves, u32 arity,
+                                                            u64 *__restrict__ out, u64 force_redo) {
+    size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_leaves) return;
+    u64 s[12];
+    const u64 *r = re + l * arity, *m = im + l * arity;
+    if (fri_leaf_sponge<false>(r, m, arity, s) | force_redo) fri_leaf_sponge<true>(r, m, arity, s);   // see poseidon.cuh: rare-repair redo
 #pragma unroll
     for (int k = 0; k < 4; k++) out[4 * l + k] = s[k];
 }
@@ -319,7 +324,7 @@ int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
         lvl[l] = (u64 *)ctx->alloc(n_dig * 4 * sizeof(u64));
         if (!lvl[l]) return ZK_ERR_OOM;
         owned[n_owned++] = lvl[l];
-        ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_kernel, g1(n_leaves), dim3(256), 0, vre[l], vim[l], n_leaves, arity, lvl[l]);
+        ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_kernel, g1(n_leaves), dim3(256), 0, vre[l], vim[l], n_leaves, arity, lvl[l], ctx->force_redo);
         zk_merkle_levels(ctx, lvl[l], n_leaves, cfg.cap_height);
         const u64 *cap = lvl[l] + 4 * zk_level_offset(n_leaves, depth - cfg.cap_height);
         u64 *pcap = d_proof + lay.o_layer_caps + (size_t)l * capw;

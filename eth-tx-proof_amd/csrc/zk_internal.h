@@ -22,6 +22,8 @@ struct zk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // test hook (env ZK_FORCE_EXACT_REDO=1): the hashing kernels take their exact-redo branch on every wave (poseidon.cuh)
+    u64 force_redo = 0;
     std::string last_error;
     // caching device allocator (stream-ordered reuse on the ctx stream)
     std::multimap<size_t, void *> free_blocks;
