@@ -119,6 +119,39 @@ GLD u64 gl_pow(u64 b, u64 e) {
 GLD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
 GLD u64 gl_root(u32 k) { return gl_pow(GL_POW2_GEN, 1ULL << (32 - k)); }  // primitive_root_of_unity(k)
 
+// Field product for the hot kernels.  Two of the repairs inside a product almost never fire: the borrow of "r - h1" (needs
+// r < 2^32) and the final canonicalisation (needs the weak result in [p, 2^64)), each about one lane in 2^32.  glx<false>
+// leaves both out -- the borrow mask of v_subbrev_co_u32 and the mask of one v_cmp_ge_u64 are OR-ed into the wave-uniform
+// sticky word `fl` by SALU instructions -- and the kernel re-runs the same input through glx<true> when fl != 0, so the
+// stored results are identical bit for bit.  16 instead of 23 VALU instructions per product.
+template <bool EXACT> struct glx {
+    u64 fl;
+    __device__ __forceinline__ u64 mul(u64 a, u64 b) {
+        if (EXACT) return gl_mul(a, b);
+        u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+        u64 A1 = (u64)a0 * b0;
+        u64 A2 = (u64)a0 * b1 + (A1 >> 32);
+        u64 A3 = (u64)a1 * b0 + (u32)A2;
+        u64 hi = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
+        u64 lo = (A3 << 32) | (u32)A1;
+        u64 r = gl_mad_eps((u32)hi, lo);
+        // the two masks go through vcc and straight into fl (SALU may read vcc right after the VALU write); general SGPR
+        // outputs here would keep dozens of mask pairs alive across the interleaved products of a butterfly network
+        u32 rl = (u32)r, rh = (u32)(r >> 32), h1 = (u32)(hi >> 32), dl, dh; u64 d;
+        asm("v_sub_co_u32 %[dl], vcc, %[rl], %[h]\n\t"
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32 %[dh], vcc, 0, %[rh], vcc\n\t"
+            "s_or_b64 %[fl], %[fl], vcc\n\t"
+            : [dl] "=&v"(dl), [dh] "=&v"(dh), [fl] "+s"(fl)
+            : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h1) : "vcc");
+        d = ((u64)dh << 32) | dl;
+        asm("v_cmp_ge_u64 vcc, %[d], %[p]\n\t"
+            "s_or_b64 %[fl], %[fl], vcc\n\t"
+            : [fl] "+s"(fl) : [d] "v"(d), [p] "s"((u64)GL_P) : "vcc");
+        return d;
+    }
+};
+
 struct gl2 { u64 a, b; };
 GLD gl2 gl2_make(u64 a, u64 b) { gl2 r; r.a = a; r.b = b; return r; }
 GLD gl2 gl2_add(gl2 x, gl2 y) { return gl2_make(gl_add(x.a, y.a), gl_add(x.b, y.b)); }

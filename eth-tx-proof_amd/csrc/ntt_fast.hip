@@ -19,8 +19,8 @@
 template <int Q> struct BR { __device__ static constexpr u32 rev(u32 i) { u32 r = 0; for (int b = 0; b < Q; b++) if (i & (1u << b)) r |= 1u << (Q - 1 - b); return r; } };
 
 // radix-2^Q network on registers x[g0 .. g0 + 2^Q); tw16[j] = w_16^j (j < 8) in the pass direction
-template <int Q, bool DIT>
-__device__ __forceinline__ void radix_net(u64 (&x)[16], const int g0, const u64 (&tw16)[8]) {
+template <int Q, bool DIT, class G>
+__device__ __forceinline__ void radix_net(G &g, u64 (&x)[16], const int g0, const u64 (&tw16)[8]) {
     if (Q == 0) return;
 #pragma unroll
     for (int s = 0; s < Q; s++) {
@@ -33,12 +33,12 @@ __device__ __forceinline__ void radix_net(u64 (&x)[16], const int g0, const u64 
             const int e16 = e << (4 - Q);                           // as a power of w_16
             u64 u = x[g0 + i], v = x[g0 + j];
             if (DIT) {
-                if (e16) v = gl_mul(v, tw16[e16]);
+                if (e16) v = g.mul(v, tw16[e16]);
                 x[g0 + i] = gl_add(u, v); x[g0 + j] = gl_sub(u, v);
             } else {
                 x[g0 + i] = gl_add(u, v);
                 u64 d = gl_sub(u, v);
-                x[g0 + j] = e16 ? gl_mul(d, tw16[e16]) : d;
+                x[g0 + j] = e16 ? g.mul(d, tw16[e16]) : d;
             }
         }
     }
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     const u32 T = 1u << TL, tid = threadIdx.x;
     const u32 nact = 1u << (W + TL - 4);
     const bool act = tid < nact;
+    const bool wact = (u32)__builtin_amdgcn_readfirstlane((int)tid) < nact;     // wave-uniform: this wave holds live lanes
     const size_t n = (size_t)1 << p.k;
     const u64 *__restrict__ RW = p.tw_full;
 
@@ -118,25 +119,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     constexpr int FIRST_DIT = P3 > 0 ? 2 : (P2 > 0 ? 1 : 0);     // first phase mapping of DIT == last phase mapping of DIF
     const int load_map = DIT ? (ROW ? 0 : FIRST_DIT) : 0;
 
-    // ---------------------------------------------------------------- load (+ input scale, + DIT pass pre-twiddle)
-    if (act) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            u32 t, slot; map_any(load_map, q, t, slot);
-            size_t c, pos; u64 v = 0;
-            if (gpos(t, slot, c, pos)) {
-                v = p.in[c * p.in_stride + pos];
-                if (p.canon_in) v = gl_canon(v);
-                if (p.load_tab) v = gl_mul(v, p.load_tab[pos]);
-                else {
-                    if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32((u32)pos, p.k) : (u32)pos; v = gl_mul(v, tab2(p.preA, p.preB, j)); }
-                    if (DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); v = gl_mul(v, tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner)); }
-                }
-            }
-            x[q] = v;
-        }
-    }
-    __syncthreads();            // shRW is complete (the data loads above were in flight meanwhile)
+    // everything from the global loads to the last butterfly, for either arithmetic (glx<false> fast / glx<true> exact)
     auto to_lds = [&](int m) {
         if (act) {
 #pragma unroll
@@ -150,21 +133,59 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
         }
     };
 
+    auto compute = [&](auto &fx) {
+    // ---------------------------------------------------------------- load (+ input scale, + DIT pass pre-twiddle)
+    // Loads (and the factor loads) are guarded per lane and issued back to back; the products run after them in wave-uniform
+    // control flow, because the sticky word of glx<false> is a scalar: inactive lanes multiply 0 by 1.
+    {
+        const bool need_mul = p.load_tab || p.preA || (DIT && S > 0);
+        u64 f[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { x[q] = 0; f[q] = 1; }
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                u32 t, slot; map_any(load_map, q, t, slot);
+                size_t c, pos;
+                if (gpos(t, slot, c, pos)) {
+                    u64 v = p.in[c * p.in_stride + pos];
+                    if (p.canon_in) v = gl_canon(v);
+                    x[q] = v;
+                    if (p.load_tab) f[q] = p.load_tab[pos];
+                    else {
+                        u64 g1 = 1;
+                        if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32((u32)pos, p.k) : (u32)pos; g1 = tab2(p.preA, p.preB, j); }
+                        if (DIT && S > 0) {
+                            u32 inner = (u32)(pos & (((size_t)1 << S) - 1));
+                            u64 g2 = tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner);
+                            g1 = p.preA ? gl_mul(g1, g2) : g2;
+                        }
+                        f[q] = g1;
+                    }
+                }
+            }
+        }
+        if (wact && need_mul) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) x[q] = fx.mul(x[q], f[q]);
+        }
+    }
+    __syncthreads();            // shRW is complete (the data loads above were in flight meanwhile)
     if (!DIT) {
         // ------------------------------------------------------------ DIF: H, M, L
-        if (act) {
-            radix_net<4, false>(x, 0, tw16);
+        if (wact) {
+            radix_net<4, false>(fx, x, 0, tw16);
             if (W > 4) {
                 u32 t, slot; map_H(0, t, slot); const u32 r = slot;          // slot of register 0 == r
 #pragma unroll
-                for (int q = 1; q < 16; q++) x[q] = gl_mul(x[q], shRW[BR<4>::rev(q) * r]);
+                for (int q = 1; q < 16; q++) x[q] = fx.mul(x[q], shRW[act ? BR<4>::rev(q) * r : 0]);
             }
         }
         if (P2 > 0) {
             to_lds(0); __syncthreads(); from_lds(1);
-            if (act) {
+            if (wact) {
 #pragma unroll
-                for (int g = 0; g < G2; g++) radix_net<P2, false>(x, g << P2, tw16);
+                for (int g = 0; g < G2; g++) radix_net<P2, false>(fx, x, g << P2, tw16);
                 if (P3 > 0) {
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
@@ -172,51 +193,59 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                         if (i == 0) continue;
                         u32 t, slot; map_M(q, t, slot);
                         u32 lo = slot & ((1u << P3) - 1);
-                        x[q] = gl_mul(x[q], shRW[(BR<P2>::rev(i) * lo) << 4]);
+                        x[q] = fx.mul(x[q], shRW[act ? (BR<P2>::rev(i) * lo) << 4 : 0]);
                     }
                 }
             }
         }
         if (P3 > 0) {
             to_lds(1); __syncthreads(); from_lds(2);
-            if (act) {
+            if (wact) {
 #pragma unroll
-                for (int g = 0; g < G3; g++) radix_net<P3, false>(x, g << P3, tw16);
+                for (int g = 0; g < G3; g++) radix_net<P3, false>(fx, x, g << P3, tw16);
             }
         }
     } else {
         // ------------------------------------------------------------ DIT: L, M, H
         if (ROW && FIRST_DIT != 0) { to_lds(0); __syncthreads(); from_lds(FIRST_DIT); }
         if (P3 > 0) {
-            if (act) {
+            if (wact) {
 #pragma unroll
-                for (int g = 0; g < G3; g++) radix_net<P3, true>(x, g << P3, tw16);
+                for (int g = 0; g < G3; g++) radix_net<P3, true>(fx, x, g << P3, tw16);
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int i = q & ((1 << P3) - 1);
                     if (i == 0) continue;
                     u32 t, slot; map_L(q, t, slot);
-                    x[q] = gl_mul(x[q], shRW[(u32)i * bitrev_u32(slot >> P3, W - P3)]);
+                    x[q] = fx.mul(x[q], shRW[act ? (u32)i * bitrev_u32(slot >> P3, W - P3) : 0]);
                 }
             }
             to_lds(2); __syncthreads(); from_lds(1);
         }
         if (P2 > 0) {
-            if (act) {
+            if (wact) {
 #pragma unroll
-                for (int g = 0; g < G2; g++) radix_net<P2, true>(x, g << P2, tw16);
+                for (int g = 0; g < G2; g++) radix_net<P2, true>(fx, x, g << P2, tw16);
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int i = q & ((1 << P2) - 1);
                     if (i == 0) continue;
                     u32 t, slot; map_M(q, t, slot);
                     u32 hi = slot >> (P2 + P3);
-                    x[q] = gl_mul(x[q], shRW[((u32)i * bitrev_u32(hi, 4)) << P3]);
+                    x[q] = fx.mul(x[q], shRW[act ? ((u32)i * bitrev_u32(hi, 4)) << P3 : 0]);
                 }
             }
             to_lds(1); __syncthreads(); from_lds(0);
         }
-        if (act) radix_net<4, true>(x, 0, tw16);
+        if (wact) radix_net<4, true>(fx, x, 0, tw16);
+    }
+
+    };
+    {
+        glx<false> gf; gf.fl = 0;
+        compute(gf);
+        // a skipped rare repair anywhere in the workgroup (waves exchange through LDS): redo the tile with every repair in place
+        if (__syncthreads_or((gf.fl != 0) | p.force_redo)) { glx<true> ge; ge.fl = 0; compute(ge); }
     }
 
     // ---------------------------------------------------------------- store
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                     u32 inner = (u32)(base & (((size_t)1 << S) - 1)) + t;
                     pos = ((size_t)bitrev_u32(inner, S) << W) + pe; K = (e << S) + inner;
                 }
-                if (p.postA) v = gl_mul(v, tab2(p.postA, p.postB, K));
+                if (p.postA) v = gl_mul(v, tab2(p.postA, p.postB, K));      // exact products: the permuting pass rarely has an output scale
                 if (p.post_const) v = gl_mul(v, p.post_const);
                 p.out[c * p.out_stride + pos] = v;
             }
@@ -265,25 +294,50 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
         return;
     }
     if (!DIT && ROW && LAST_DIF != 0) { __syncthreads(); to_lds(LAST_DIF); __syncthreads(); from_lds(0); smap = 0; }
-    if (act) {
+    // same structure as the load side: guarded batched factor loads, products in wave-uniform control flow, guarded stores;
+    // x[] is left intact, so a flagged wave runs the loop again with exact products and overwrites what it stored
+    auto store_plain = [&](auto &fx) {
+        const bool need_mul = p.store_tab || (!DIT && S > 0) || p.postA || p.post_const;
+        u64 f[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) f[q] = 1;
+        if (act && need_mul) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                u32 t, slot; map_any(smap, q, t, slot);
+                size_t c, pos;
+                if (!gpos(t, slot, c, pos)) continue;
+                if (p.store_tab) f[q] = p.store_tab[pos];
+                else {
+                    const u32 e = DIT ? slot : bitrev_u32(slot, W);
+                    u64 g1 = 1; bool have = false;
+                    if (!DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); g1 = tab2(p.twA, p.twB, e * inner); have = true; }
+                    if (p.postA) {
+                        u32 K = ROW ? (u32)(((pos >> W) << W) + e) : (u32)(((base >> (W + S)) << (W + S)) + ((size_t)e << S) + (pos & (((size_t)1 << S) - 1)));
+                        u64 g2 = tab2(p.postA, p.postB, K);
+                        g1 = have ? gl_mul(g1, g2) : g2; have = true;
+                    }
+                    if (p.post_const) g1 = have ? gl_mul(g1, p.post_const) : p.post_const;
+                    f[q] = g1;
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            u32 t, slot; map_any(smap, q, t, slot);
-            size_t c, pos;
-            if (!gpos(t, slot, c, pos)) continue;
             u64 v = x[q];
-            const u32 e = DIT ? slot : bitrev_u32(slot, W);
-            if (p.store_tab) v = gl_mul(v, p.store_tab[pos]);
-            else {
-                if (!DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); v = gl_mul(v, tab2(p.twA, p.twB, e * inner)); }
-                if (p.postA) {
-                    u32 K = ROW ? (u32)(((pos >> W) << W) + e) : (u32)(((base >> (W + S)) << (W + S)) + ((size_t)e << S) + (pos & (((size_t)1 << S) - 1)));
-                    v = gl_mul(v, tab2(p.postA, p.postB, K));
-                }
-                if (p.post_const) v = gl_mul(v, p.post_const);
+            if (wact && need_mul) v = fx.mul(v, f[q]);
+            if (act) {
+                u32 t, slot; map_any(smap, q, t, slot);
+                size_t c, pos;
+                if (!gpos(t, slot, c, pos)) continue;
+                p.out[c * p.out_stride + pos] = v;
             }
-            p.out[c * p.out_stride + pos] = v;
         }
+    };
+    {
+        glx<false> gf; gf.fl = 0;
+        store_plain(gf);
+        if ((gf.fl != 0) | p.force_redo) { glx<true> ge; ge.fl = 0; store_plain(ge); }
     }
 }
 
@@ -346,6 +400,7 @@ static bool launch_dr(zk_ctx *ctx, const PassParams &p, const char *name) {
 bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, const char *name) {
     if (p0.W < 4 || p0.W > 10 || p0.W + p0.TL > 13 || !p0.tw_full) return false;
     PassParams p = p0;
+    p.force_redo = (int)ctx->force_redo;
     bool need_load = p.preA || (dit && p.S > 0);
     bool need_store = !p.permute_out && ((!dit && p.S > 0) || p.postA || p.post_const);
     // the DIT post table is indexed by the natural output index, which equals the output position only when not permuting

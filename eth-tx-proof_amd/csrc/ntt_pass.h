@@ -20,6 +20,7 @@ struct PassParams {
     // register-radix kernel only: every per-position factor of the pass folded into one coalesced table each
     const u64 *load_tab;            // multiply the element loaded from position pos by load_tab[pos]  (or NULL)
     const u64 *store_tab;           // multiply the element stored to position pos by store_tab[pos]  (or NULL)
+    int force_redo;                 // test hook: take the exact-redo branch in every workgroup (ctx->force_redo)
     int col_fast;                   // blockIdx -> (tile, column) with the column fastest, so table slices stay in L2
 };
 
