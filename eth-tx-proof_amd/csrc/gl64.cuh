@@ -4,8 +4,13 @@
 // Invariant: every value stored to memory is canonical (< p).  add/sub/mul take canonical inputs and
 // return canonical outputs; gl_canon() is applied once where caller-supplied data enters.
 #pragma once
+#if !defined(__HIPCC_RTC__)      // hiprtc (the constraint-program JIT, prover_quotient_jit.hip) has the runtime header built in
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef unsigned long uint64_t;
+typedef unsigned int uint32_t;
+#endif
 
 typedef uint64_t u64;
 typedef uint32_t u32;

@@ -20,6 +20,11 @@ int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc 
 int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &cfg, const zk_batch *trace, const zk_batch *aux,
                         const u64 *d_public, const u64 *d_chal, const u64 *d_alphas, u64 *d_qcoeffs);
 
+// prover_quotient_jit.hip: the constraint program compiled to gfx950 code (hiprtc); same results as the interpreter
+struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 pad; };
+bool zk_quotient_jit_enabled(const zk_ctx *ctx, size_t L);
+int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, QJitParams &p);
+
 // prover_fri.hip: PolynomialBatch::prove_openings + fri_proof, everything written into the device proof buffer
 struct FriLayout {           // offsets (in words) into the proof buffer, per table
     size_t o_local, o_next, o_aux, o_auxn, o_zs, o_q;     // openings

@@ -125,8 +125,17 @@ int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &c
     u64 gn = gl_pow(GL_GEN, n), wr = gl_root(rate_bits);
     for (u32 i = 0; i < (1u << rate_bits); i++) p.zh_inv[i] = gl_inv(gl_sub(gl_mul(gn, gl_pow(wr, i)), 1));
     p.out = d_qcoeffs;
-    size_t shmem = (size_t)(air.host->n_regs ? air.host->n_regs : 1) * 256 * sizeof(u64);
-    ZK_LAUNCH(ctx, "quotient_eval", quotient_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), shmem, p);
+    if (zk_quotient_jit_enabled(ctx, L)) {
+        QJitParams jp = {};
+        jp.trace_lde = p.trace_lde; jp.aux_lde = p.aux_lde; jp.pub = p.pub; jp.chal = p.chal; jp.alphas = p.alphas; jp.lag = p.lag;
+        jp.xA = p.xA; jp.xB = p.xB; jp.out = p.out; jp.L = L; jp.last_inv = p.last_inv; jp.lgL = lgL;
+        for (int i = 0; i < 8; i++) jp.zh_inv[i] = p.zh_inv[i];
+        rc = zk_quotient_jit_launch(ctx, air.host, p.C, p.A, nch, rate_bits, jp);
+        if (rc) return rc;
+    } else {
+        size_t shmem = (size_t)(air.host->n_regs ? air.host->n_regs : 1) * 256 * sizeof(u64);
+        ZK_LAUNCH(ctx, "quotient_eval", quotient_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), shmem, p);
+    }
     // coset_ifft(g): leaf-order values -> natural-order coefficients, scaled by L^-1 g^-j.  In place.
     TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);
     return zk_ntt_dit(ctx, d_qcoeffs, L, d_qcoeffs, L, lgL, nch, 1, nullptr, &post, 0, nullptr, 0);

@@ -1,0 +1,153 @@
+// Constraint programs compiled to gfx950 code.
+// Upstream, a table's constraints are Rust code (`Stark::eval_packed_generic`, starky 0.4.0 / evm_arithmetization 0.1.3,
+// pinned at /root/reference/Cargo.lock:4529-4531, 1675-1677) monomorphised when the prover is built; the reference builds
+// its prover state once at start-up (/root/reference/common/src/prover_state/mod.rs:59-95).  Here the constraints arrive
+// as data (zk_air), and the counterpart of that build step is: turn the straight-line program into HIP source, compile it
+// with hiprtc for gfx950, keep the module.  The generated kernel does exactly what the bytecode interpreter in
+// prover_quotient.hip does -- same field operations in the same order, so the same bits -- without the per-instruction
+// fetch / decode / LDS round trip: temporaries live in VGPRs, constants are immediates, every column is loaded once.
+// Small tables (and ZK_QUOTIENT_JIT=0) stay on the interpreter.
+#include <hip/hiprtc.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "zk_internal.h"
+#include "prover.h"
+
+static const char GL64_SRC[] =
+#include "gl64_src.inc"
+    ;
+
+namespace {
+struct JitKernel { hipModule_t mod; hipFunction_t fn; };
+std::mutex g_mu;
+std::map<std::string, JitKernel> g_cache;
+
+void appendf(std::string &s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void appendf(std::string &s, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); int n = vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    s.append(buf, (size_t)(n < (int)sizeof buf ? n : (int)sizeof buf - 1));
+}
+
+// C++ expression for an operand; emits the (single) load of a column / public input / challenge at its first use
+struct Gen {
+    const zk_air *air; u32 C, A;
+    std::string body;
+    std::vector<char> have_l, have_n, have_pub, have_ch;
+    std::string opnd(u32 o) {
+        u32 kind = o >> 24, idx = o & 0xFFFFFF;
+        char name[64];
+        switch (kind) {
+        case ZK_OPND_REG: snprintf(name, sizeof name, "r%u", idx); return name;
+        case ZK_OPND_LOCAL:
+        case ZK_OPND_NEXT: {
+            const bool nx = kind == ZK_OPND_NEXT;
+            std::vector<char> &have = nx ? have_n : have_l;
+            snprintf(name, sizeof name, "%c%u", nx ? 'n' : 'l', idx);
+            if (!have[idx]) {
+                have[idx] = 1;
+                if (idx < C) appendf(body, "    const u64 %s = p.trace_lde[%uull * p.L + %s];\n", name, idx, nx ? "sn" : "s");
+                else appendf(body, "    const u64 %s = p.aux_lde[%uull * p.L + %s];\n", name, idx - C, nx ? "sn" : "s");
+            }
+            return name;
+        }
+        case ZK_OPND_CONST: snprintf(name, sizeof name, "0x%llxull", (unsigned long long)gl_canon(air->constants[idx])); return name;
+        case ZK_OPND_PUBLIC:
+            snprintf(name, sizeof name, "pub%u", idx);
+            if (!have_pub[idx]) { have_pub[idx] = 1; appendf(body, "    const u64 %s = p.pub[%u];\n", name, idx); }
+            return name;
+        default:
+            snprintf(name, sizeof name, "ch%u", idx);
+            if (idx >= have_ch.size()) have_ch.resize(idx + 1, 0);
+            if (!have_ch[idx]) { have_ch[idx] = 1; appendf(body, "    const u64 %s = p.chal[%u];\n", name, idx); }
+            return name;
+        }
+    }
+};
+
+std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits) {
+    Gen g; g.air = air; g.C = C; g.A = A;
+    g.have_l.assign(C + A, 0); g.have_n.assign(C + A, 0); g.have_pub.assign(air->n_public_inputs + 1, 0);
+    for (u32 pc = 0; pc < air->n_instrs; pc++) {
+        const zk_instr &in = air->instrs[pc];
+        std::string a = g.opnd(in.a);
+        if (in.op <= ZK_OP_MUL) {
+            std::string b = g.opnd(in.b);
+            appendf(g.body, "    r%u = %s(%s, %s);\n", in.dst & 0xFFFFFF, in.op == ZK_OP_ADD ? "gl_add" : in.op == ZK_OP_SUB ? "gl_sub" : "gl_mul",
+                    a.c_str(), b.c_str());
+        } else {
+            const char *f = in.op == ZK_OP_EMIT_TRANSITION ? "z_last" : in.op == ZK_OP_EMIT_FIRST ? "l_first" : in.op == ZK_OP_EMIT_LAST ? "l_last" : nullptr;
+            if (f) appendf(g.body, "    { const u64 c = gl_mul(%s, %s);", a.c_str(), f);
+            else appendf(g.body, "    { const u64 c = %s;", a.c_str());
+            for (u32 j = 0; j < nch; j++) appendf(g.body, " acc%u = gl_mul_add(acc%u, al%u, c);", j, j, j);
+            g.body += " }\n";
+        }
+    }
+    std::string s;
+    s += "#include \"gl64.cuh\"\n";
+    s += "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 pad; };\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void quotient_jit(QJitParams p) {\n";
+    s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
+    s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
+    appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
+    s += "    const u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);\n    const u64 z_last = gl_sub(x, p.last_inv);\n";
+    s += "    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = 0; const u64 al%u = p.alphas[%u];\n", j, j, j);
+    for (u32 r = 0; r < air->n_regs; r++) appendf(s, "    u64 r%u = 0;\n", r);
+    s += g.body;
+    appendf(s, "    const u64 zi = p.zh_inv[i & %uu];\n", (1u << rate_bits) - 1);
+    for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = gl_mul(acc%u, zi);\n", j, j);
+    s += "}\n";
+    return s;
+}
+}  // namespace
+
+bool zk_quotient_jit_enabled(const zk_ctx *ctx, size_t L) {
+    return ctx->quotient_jit_mode == 2 || (ctx->quotient_jit_mode == 1 && L >= ((size_t)1 << ctx->quotient_jit_min_log));
+}
+
+int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, QJitParams &p) {
+    // cache key: everything the generated source depends on, verbatim
+    std::string key;
+    u32 hdr[8] = {(u32)ctx->device, C, A, nch, rate_bits, air->n_regs, air->n_instrs, air->n_constants};
+    key.append((const char *)hdr, sizeof hdr);
+    key.append((const char *)air->instrs, (size_t)air->n_instrs * sizeof(zk_instr));
+    key.append((const char *)air->constants, (size_t)air->n_constants * sizeof(u64));
+    JitKernel k;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_cache.find(key);
+        if (it == g_cache.end()) {
+            std::string src = generate(air, C, A, nch, rate_bits);
+            hiprtcProgram prog;
+            const char *hs[] = {GL64_SRC}, *hn[] = {"gl64.cuh"};
+            if (hiprtcCreateProgram(&prog, src.c_str(), "quotient_jit.hip", 1, hs, hn) != HIPRTC_SUCCESS)
+                return ctx->fail(ZK_ERR_HIP, "quotient jit: hiprtcCreateProgram failed");
+            const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+            hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+            if (r != HIPRTC_SUCCESS) {
+                size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
+                std::string log(ls + 1, 0); hiprtcGetProgramLog(prog, &log[0]);
+                hiprtcDestroyProgram(&prog);
+                return ctx->fail(ZK_ERR_HIP, ("quotient jit: compile failed: " + log.substr(0, 400)).c_str());
+            }
+            size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+            std::vector<char> code(cs); hiprtcGetCode(prog, code.data());
+            hiprtcDestroyProgram(&prog);
+            if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: hipModuleLoadData failed");
+            if (hipModuleGetFunction(&k.fn, k.mod, "quotient_jit") != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: kernel not found in module");
+            g_cache.emplace(key, k);
+        } else k = it->second;
+    }
+    void *args[] = {&p};
+    const unsigned blocks = (unsigned)((p.L + 255) / 256);
+    hipError_t e;
+    { ProfScope ps(ctx, "quotient_eval"); e = hipModuleLaunchKernel(k.fn, blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr); }
+    if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: launch failed");
+    return ZK_OK;
+}

@@ -24,6 +24,9 @@ struct zk_ctx {
     bool own_stream = false;
     // test hook (env ZK_FORCE_EXACT_REDO=1): the hashing kernels take their exact-redo branch on every wave (poseidon.cuh)
     u64 force_redo = 0;
+    // constraint-program JIT (prover_quotient_jit.hip): env ZK_QUOTIENT_JIT = 0 off / 1 tables with >= 2^ZK_QUOTIENT_JIT_MIN_LOG
+    // coset points (default 17) / 2 always; read when the context is created
+    int quotient_jit_mode = 1, quotient_jit_min_log = 17;
     std::string last_error;
     // caching device allocator (stream-ordered reuse on the ctx stream)
     std::multimap<size_t, void *> free_blocks;

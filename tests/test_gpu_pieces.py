@@ -185,3 +185,32 @@ def test_fri_instance_error_paths(ctx, zk):
     assert e.value.code == -8
     # a valid call still works afterwards
     assert zk.fri_prove_instance(ctx, cfg, [b], [((5, 6), [(0, 0), (0, 2)])], c).size > 0
+
+
+@pytest.mark.parametrize("n_cols,n_helpers,log_n", [(6, 2, 7), (93, 19, 9), (7, 0, 8), (21, 5, 10)])
+def test_quotient_jit_equals_interpreter_and_oracle(zk, orc, monkeypatch, n_cols, n_helpers, log_n):
+    """the constraint program compiled with hiprtc (ZK_QUOTIENT_JIT=2: always) and the bytecode interpreter (=0) produce the
+    oracle's quotient polynomials bit for bit"""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    rng = np.random.default_rng(log_n)
+    prog = air.cpu_like_air(n_cols, n_helpers)
+    tr, pub = orc.synth_trace(n_cols, log_n, 5)
+    ch, al = field_rand(rng, 4), field_rand(rng, 2)
+    ob = orc.Batch(tr)
+    oab = aux = None
+    if n_helpers:
+        rc, aux = orc.aux_columns(prog, ch, tr)
+        assert rc == 0
+        oab = orc.Batch(aux)
+    ref = orc.quotient(cfg, prog, ob, oab, pub, ch, al)
+    for mode in ("2", "0"):
+        monkeypatch.setenv("ZK_QUOTIENT_JIT", mode)
+        c2 = zk.Context(0)
+        try:
+            tb = c2.batch_from_values(tr)
+            ab = c2.batch_from_values(aux) if n_helpers else None
+            got = zk.quotient(c2, cfg, prog, tb, ab, pub, ch, al)
+            assert (got == ref).all(), mode
+        finally:
+            c2.close()
