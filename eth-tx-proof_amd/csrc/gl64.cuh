@@ -139,6 +139,10 @@ template <bool EXACT> struct glx {
         u64 A3 = (u64)a1 * b0 + (u32)A2;
         u64 hi = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
         u64 lo = (A3 << 32) | (u32)A1;
+        return tail(lo, hi);
+    }
+    // hi:lo -> canonical residue unless a rare repair was skipped (then fl != 0)
+    __device__ __forceinline__ u64 tail(u64 lo, u64 hi) {
         u64 r = gl_mad_eps((u32)hi, lo);
         // the two masks go through vcc and straight into fl (SALU may read vcc right after the VALU write); general SGPR
         // outputs here would keep dozens of mask pairs alive across the interleaved products of a butterfly network
@@ -154,6 +158,19 @@ template <bool EXACT> struct glx {
             "s_or_b64 %[fl], %[fl], vcc\n\t"
             : [fl] "+s"(fl) : [d] "v"(d), [p] "s"((u64)GL_P) : "vcc");
         return d;
+    }
+    // a*b + c (c canonical)
+    __device__ __forceinline__ u64 mul_add(u64 a, u64 b, u64 c) {
+        if (EXACT) return gl_mul_add(a, b, c);
+        u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+        u64 A1 = (u64)a0 * b0;
+        u64 A2 = (u64)a0 * b1 + (A1 >> 32);
+        u64 A3 = (u64)a1 * b0 + (u32)A2;
+        u64 hi = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
+        u64 lo = (A3 << 32) | (u32)A1;
+        u64 l2 = lo + c;
+        hi += (l2 < lo);
+        return tail(l2, hi);
     }
 };
 

@@ -37,10 +37,10 @@ __device__ __forceinline__ u64 q_fetch(const QParams &p, u32 o, const u64 *sh, u
     }
 }
 
-__global__ __launch_bounds__(256) void quotient_kernel(QParams p) {
-    extern __shared__ u64 sh[];
+// one workgroup-sized slice of the coset (256 points from `block`*256) through the bytecode interpreter
+__device__ __forceinline__ void quotient_block(const QParams &p, u32 block, u64 *sh) {
     const u32 t = threadIdx.x;
-    const size_t s = (size_t)blockIdx.x * 256 + t;
+    const size_t s = (size_t)block * 256 + t;
     if (s >= p.L) return;
     const u32 i = bitrev_u32((u32)s, p.lgL);
     const size_t sn = bitrev_u32((i + (1u << p.rate_bits)) & (u32)(p.L - 1), p.lgL);
@@ -70,6 +70,22 @@ __global__ __launch_bounds__(256) void quotient_kernel(QParams p) {
     const u64 zi = p.zh_inv[i & ((1u << p.rate_bits) - 1)];
 #pragma unroll
     for (int j = 0; j < 4; j++) if (j < (int)p.nch) p.out[(size_t)j * p.L + s] = gl_mul(acc[j], zi);
+}
+__global__ __launch_bounds__(256) void quotient_kernel(QParams p) {
+    extern __shared__ u64 sh[];
+    quotient_block(p, blockIdx.x, sh);
+}
+// Exact redo of the slices in which the compiled kernel (prover_quotient_jit.hip) skipped a rare repair: redo[0] = number of
+// pushed slice ids, redo[1..cap] = the ids.  More pushes than `cap` (never seen; forced by the test hook): every slice.
+__global__ __launch_bounds__(256) void quotient_fixup_kernel(QParams p, const u32 *redo, u32 cap, u32 total_blocks) {
+    extern __shared__ u64 sh[];
+    const u32 count = redo[0];
+    if (count == 0) return;
+    if (count <= cap) {
+        for (u32 k = blockIdx.x; k < count; k += gridDim.x) { quotient_block(p, redo[1 + k], sh); __syncthreads(); }
+    } else {
+        for (u32 b = blockIdx.x; b < total_blocks; b += gridDim.x) { quotient_block(p, b, sh); __syncthreads(); }
+    }
 }
 
 __global__ void canon_copy_kernel(const u64 *in, u64 *out, u32 n) {
@@ -125,17 +141,29 @@ int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &c
     u64 gn = gl_pow(GL_GEN, n), wr = gl_root(rate_bits);
     for (u32 i = 0; i < (1u << rate_bits); i++) p.zh_inv[i] = gl_inv(gl_sub(gl_mul(gn, gl_pow(wr, i)), 1));
     p.out = d_qcoeffs;
+    const size_t shmem = (size_t)(air.host->n_regs ? air.host->n_regs : 1) * 256 * sizeof(u64);
+    const unsigned blocks = (unsigned)((L + 255) / 256);
+    bool done = false;
     if (zk_quotient_jit_enabled(ctx, L)) {
+        const u32 cap = 1024;
+        u32 *redo = (u32 *)ctx->alloc((cap + 1) * sizeof(u32));
+        if (!redo) return ZK_ERR_OOM;
+        hipMemsetAsync(redo, 0, sizeof(u32), ctx->stream);
         QJitParams jp = {};
         jp.trace_lde = p.trace_lde; jp.aux_lde = p.aux_lde; jp.pub = p.pub; jp.chal = p.chal; jp.alphas = p.alphas; jp.lag = p.lag;
         jp.xA = p.xA; jp.xB = p.xB; jp.out = p.out; jp.L = L; jp.last_inv = p.last_inv; jp.lgL = lgL;
+        jp.redo = redo; jp.redo_cap = cap; jp.force = (u32)ctx->force_redo;
         for (int i = 0; i < 8; i++) jp.zh_inv[i] = p.zh_inv[i];
         rc = zk_quotient_jit_launch(ctx, air.host, p.C, p.A, nch, rate_bits, jp);
-        if (rc) return rc;
-    } else {
-        size_t shmem = (size_t)(air.host->n_regs ? air.host->n_regs : 1) * 256 * sizeof(u64);
-        ZK_LAUNCH(ctx, "quotient_eval", quotient_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), shmem, p);
+        if (rc == ZK_OK) {
+            // slices in which the compiled kernel skipped a rare repair are recomputed by the interpreter (normally none or one)
+            ZK_LAUNCH(ctx, "quotient_fixup", quotient_fixup_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), shmem, p, (const u32 *)redo, cap, blocks);
+            done = true;
+        }
+        ctx->release(redo);
+        if (rc != ZK_OK && rc != ZK_JIT_UNAVAILABLE) return rc;
     }
+    if (!done) ZK_LAUNCH(ctx, "quotient_eval", quotient_kernel, dim3(blocks), dim3(256), shmem, p);
     // coset_ifft(g): leaf-order values -> natural-order coefficients, scaled by L^-1 g^-j.  In place.
     TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);
     return zk_ntt_dit(ctx, d_qcoeffs, L, d_qcoeffs, L, lgL, nch, 1, nullptr, &post, 0, nullptr, 0);

@@ -78,30 +78,32 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits) {
         std::string a = g.opnd(in.a);
         if (in.op <= ZK_OP_MUL) {
             std::string b = g.opnd(in.b);
-            appendf(g.body, "    r%u = %s(%s, %s);\n", in.dst & 0xFFFFFF, in.op == ZK_OP_ADD ? "gl_add" : in.op == ZK_OP_SUB ? "gl_sub" : "gl_mul",
+            appendf(g.body, "    r%u = %s(%s, %s);\n", in.dst & 0xFFFFFF, in.op == ZK_OP_ADD ? "gl_add" : in.op == ZK_OP_SUB ? "gl_sub" : "g.mul",
                     a.c_str(), b.c_str());
         } else {
             const char *f = in.op == ZK_OP_EMIT_TRANSITION ? "z_last" : in.op == ZK_OP_EMIT_FIRST ? "l_first" : in.op == ZK_OP_EMIT_LAST ? "l_last" : nullptr;
-            if (f) appendf(g.body, "    { const u64 c = gl_mul(%s, %s);", a.c_str(), f);
+            if (f) appendf(g.body, "    { const u64 c = g.mul(%s, %s);", a.c_str(), f);
             else appendf(g.body, "    { const u64 c = %s;", a.c_str());
-            for (u32 j = 0; j < nch; j++) appendf(g.body, " acc%u = gl_mul_add(acc%u, al%u, c);", j, j, j);
+            for (u32 j = 0; j < nch; j++) appendf(g.body, " acc%u = g.mul_add(acc%u, al%u, c);", j, j, j);
             g.body += " }\n";
         }
     }
     std::string s;
     s += "#include \"gl64.cuh\"\n";
-    s += "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 pad; };\n";
+    s += "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u32 *redo; u32 redo_cap; u32 pad; };\n";
     s += "extern \"C\" __global__ __launch_bounds__(256) void quotient_jit(QJitParams p) {\n";
     s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
     s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
     appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
     s += "    const u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);\n    const u64 z_last = gl_sub(x, p.last_inv);\n";
     s += "    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];\n";
+    s += "    glx<false> g; g.fl = 0;      // products without the two 1-in-2^32 repairs; a flagged slice is redone by the interpreter\n";
     for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = 0; const u64 al%u = p.alphas[%u];\n", j, j, j);
     for (u32 r = 0; r < air->n_regs; r++) appendf(s, "    u64 r%u = 0;\n", r);
     s += g.body;
     appendf(s, "    const u64 zi = p.zh_inv[i & %uu];\n", (1u << rate_bits) - 1);
-    for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = gl_mul(acc%u, zi);\n", j, j);
+    for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = g.mul(acc%u, zi);\n", j, j);
+    s += "    if ((g.fl != 0) | p.force) {\n        if ((threadIdx.x & 63) == 0) { u32 k = atomicAdd(p.redo, 1u); if (k < p.redo_cap) p.redo[1 + k] = blockIdx.x; }\n    }\n";
     s += "}\n";
     return s;
 }
@@ -124,6 +126,9 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
         auto it = g_cache.find(key);
         if (it == g_cache.end()) {
             std::string src = generate(air, C, A, nch, rate_bits);
+            if (const char *dump = getenv("ZK_QUOTIENT_JIT_DUMP")) {       // debugging aid: the generated source, for offline inspection
+                if (FILE *f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
+            }
             hiprtcProgram prog;
             const char *hs[] = {GL64_SRC}, *hn[] = {"gl64.cuh"};
             if (hiprtcCreateProgram(&prog, src.c_str(), "quotient_jit.hip", 1, hs, hn) != HIPRTC_SUCCESS)
@@ -141,9 +146,14 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
             hiprtcDestroyProgram(&prog);
             if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: hipModuleLoadData failed");
             if (hipModuleGetFunction(&k.fn, k.mod, "quotient_jit") != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: kernel not found in module");
+            // A generated kernel that spills to scratch is not used: with several streams in flight such kernels ended in GPU
+            // memory faults on this stack (seen with __launch_bounds__(256, 4), 264 B of scratch); the interpreter takes over.
+            int scratch = 0;
+            if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.fn) != hipSuccess || scratch > 0) k.fn = nullptr;
             g_cache.emplace(key, k);
         } else k = it->second;
     }
+    if (!k.fn) return ZK_JIT_UNAVAILABLE;
     void *args[] = {&p};
     const unsigned blocks = (unsigned)((p.L + 255) / 256);
     hipError_t e;

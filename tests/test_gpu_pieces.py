@@ -204,8 +204,9 @@ def test_quotient_jit_equals_interpreter_and_oracle(zk, orc, monkeypatch, n_cols
         assert rc == 0
         oab = orc.Batch(aux)
     ref = orc.quotient(cfg, prog, ob, oab, pub, ch, al)
-    for mode in ("2", "0"):
-        monkeypatch.setenv("ZK_QUOTIENT_JIT", mode)
+    for mode in ("2", "0", "2+forced redo"):       # the last: every slice flagged -> all redone by the interpreter fix-up
+        monkeypatch.setenv("ZK_QUOTIENT_JIT", mode[0])
+        monkeypatch.setenv("ZK_FORCE_EXACT_REDO", "1" if "forced" in mode else "0")
         c2 = zk.Context(0)
         try:
             tb = c2.batch_from_values(tr)
