@@ -129,48 +129,59 @@ GLD u64 gl_root(u32 k) { return gl_pow(GL_POW2_GEN, 1ULL << (32 - k)); }  // pri
 // leaves both out -- the borrow mask of v_subbrev_co_u32 and the mask of one v_cmp_ge_u64 are OR-ed into the wave-uniform
 // sticky word `fl` by SALU instructions -- and the kernel re-runs the same input through glx<true> when fl != 0, so the
 // stored results are identical bit for bit.  16 instead of 23 VALU instructions per product.
+// x + acc as ONE v_mad_u64_u32 (x*1 + acc): adds a 32-bit word to a 64-bit pair without first building the zero-extended
+// register pair {x, 0} (one or two v_mov_b32 each time hipcc does it from the C++ spelling)
+__device__ __forceinline__ u64 gl_madd1(u32 x, u64 acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r, k;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(r), "=s"(k) : "v"(x), "v"(acc));
+    return r;
+#else
+    return acc + x;
+#endif
+}
 template <bool EXACT> struct glx {
     u64 fl;
+    // a*b = lo + hi*2^64 + cy*2^96: six v_mad_u64_u32; the mid column a0*b1 + a1*b0 keeps its carry-out as the lane mask cy
+    // (2^96 = -1: it becomes the borrow-in of the last subtraction) instead of being propagated
     __device__ __forceinline__ u64 mul(u64 a, u64 b) {
         if (EXACT) return gl_mul(a, b);
         u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-        u64 A1 = (u64)a0 * b0;
-        u64 A2 = (u64)a0 * b1 + (A1 >> 32);
-        u64 A3 = (u64)a1 * b0 + (u32)A2;
-        u64 hi = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
-        u64 lo = (A3 << 32) | (u32)A1;
-        return tail(lo, hi);
+        u64 P0 = (u64)a0 * b0;
+        u64 A2 = gl_madd1((u32)(P0 >> 32), (u64)a0 * b1);
+        u64 X, cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(X), "=s"(cy) : "v"(a1), "v"(b0), "v"(A2));
+        u64 A4 = gl_madd1((u32)(X >> 32), (u64)a1 * b1);
+        return tail((X << 32) | (u32)P0, A4, cy);
     }
-    // hi:lo -> canonical residue unless a rare repair was skipped (then fl != 0)
-    __device__ __forceinline__ u64 tail(u64 lo, u64 hi) {
+    // lo + hi*2^64 - cy  ->  canonical residue unless a rare repair was skipped (then fl != 0)
+    __device__ __forceinline__ u64 tail(u64 lo, u64 hi, u64 cy) {
         u64 r = gl_mad_eps((u32)hi, lo);
         // the two masks go through vcc and straight into fl (SALU may read vcc right after the VALU write); general SGPR
         // outputs here would keep dozens of mask pairs alive across the interleaved products of a butterfly network
         u32 rl = (u32)r, rh = (u32)(r >> 32), h1 = (u32)(hi >> 32), dl, dh; u64 d;
-        asm("v_sub_co_u32 %[dl], vcc, %[rl], %[h]\n\t"
+        asm("v_subb_co_u32 %[dl], vcc, %[rl], %[h], %[cy]\n\t"
             "s_nop 1\n\t"
             "v_subbrev_co_u32 %[dh], vcc, 0, %[rh], vcc\n\t"
             "s_or_b64 %[fl], %[fl], vcc\n\t"
             : [dl] "=&v"(dl), [dh] "=&v"(dh), [fl] "+s"(fl)
-            : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h1) : "vcc");
+            : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h1), [cy] "s"(cy) : "vcc");
         d = ((u64)dh << 32) | dl;
         asm("v_cmp_ge_u64 vcc, %[d], %[p]\n\t"
             "s_or_b64 %[fl], %[fl], vcc\n\t"
             : [fl] "+s"(fl) : [d] "v"(d), [p] "s"((u64)GL_P) : "vcc");
         return d;
     }
-    // a*b + c (c canonical)
+    // a*b + c (c canonical): c's words join the first two columns ((2^32-1)^2 + 2(2^32-1) = 2^64-1: no overflow)
     __device__ __forceinline__ u64 mul_add(u64 a, u64 b, u64 c) {
         if (EXACT) return gl_mul_add(a, b, c);
         u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-        u64 A1 = (u64)a0 * b0;
-        u64 A2 = (u64)a0 * b1 + (A1 >> 32);
-        u64 A3 = (u64)a1 * b0 + (u32)A2;
-        u64 hi = (u64)a1 * b1 + (A2 >> 32) + (A3 >> 32);
-        u64 lo = (A3 << 32) | (u32)A1;
-        u64 l2 = lo + c;
-        hi += (l2 < lo);
-        return tail(l2, hi);
+        u64 P0 = gl_madd1((u32)c, (u64)a0 * b0);
+        u64 A2 = gl_madd1((u32)(c >> 32), gl_madd1((u32)(P0 >> 32), (u64)a0 * b1));
+        u64 X, cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(X), "=s"(cy) : "v"(a1), "v"(b0), "v"(A2));
+        u64 A4 = gl_madd1((u32)(X >> 32), (u64)a1 * b1);
+        return tail((X << 32) | (u32)P0, A4, cy);
     }
 };
 

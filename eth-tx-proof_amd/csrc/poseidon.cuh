@@ -18,6 +18,8 @@
 
 namespace psd {
 
+PSD_CONST u64 PSD_ZERO12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
 // 64x64 -> 128 with four v_mad_u64_u32 (the running sums never overflow 64 bits)
 __device__ __forceinline__ void mul128(u64 a, u64 b, u64 &lo, u64 &hi) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
@@ -102,8 +104,40 @@ struct acc3 {
 // ~19 VALU instructions of every product.  core<false> skips it: the borrow mask that v_subbrev_co_u32 delivers anyway is
 // OR-ed into a wave-uniform sticky word `fl` with one SALU instruction, and the kernel that ran the fast path re-runs the
 // same input through core<true> (all repairs in place) when fl != 0 -- results are identical either way, bit for bit.
+// x + acc as ONE v_mad_u64_u32 (x*1 + acc): adds a 32-bit word to a 64-bit pair.  The C++ spelling (u64)x + acc makes hipcc
+// build the zero-extended register pair {x, 0} first -- one or two v_mov_b32 per addition, a third of a full round.
+__device__ __forceinline__ u64 madd1(u32 x, u64 acc) {
+    u64 r, k;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(r), "=s"(k) : "v"(x), "v"(acc));
+    return r;
+}
+
 template <bool EXACT> struct core {
     u64 fl;
+    // r - h - (cin ? 1 : 0), cin a lane mask (the carry-out of a v_mad_u64_u32, weight 2^96 = -1)
+    __device__ __forceinline__ u64 sub32c(u64 r, u32 h, u64 cin) {
+        u32 rl = (u32)r, rh = (u32)(r >> 32), dl, dh; u64 k;
+        if (EXACT) {
+            // borrow out of the 64-bit subtraction: the true value is negative, + p = - eps (mod 2^64)
+            u32 m;
+            asm("v_subb_co_u32 %[dl], %[k], %[rl], %[h], %[c]\n\t"
+                "s_nop 1\n\t"
+                "v_subbrev_co_u32 %[dh], %[k], 0, %[rh], %[k]\n\t"
+                "s_nop 1\n\t"
+                "v_cndmask_b32_e64 %[m], 0, -1, %[k]\n\t"
+                : [dl] "=&v"(dl), [dh] "=&v"(dh), [k] "=&s"(k), [m] "=&v"(m)
+                : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h), [c] "s"(cin));
+            return (((u64)dh << 32) | dl) - (u64)m;
+        } else {
+            asm("v_subb_co_u32 %[dl], %[k], %[rl], %[h], %[c]\n\t"
+                "s_nop 1\n\t"
+                "v_subbrev_co_u32 %[dh], %[k], 0, %[rh], %[k]\n\t"
+                : [dl] "=&v"(dl), [dh] "=&v"(dh), [k] "=&s"(k)
+                : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h), [c] "s"(cin));
+            fl |= k;
+            return ((u64)dh << 32) | dl;
+        }
+    }
     __device__ __forceinline__ u64 sub32(u64 r, u32 h) {
         if (EXACT) {
             u64 d; bool b = __builtin_sub_overflow(r, (u64)h, &d);
@@ -120,12 +154,29 @@ template <bool EXACT> struct core {
         }
     }
     __device__ __forceinline__ u64 red128(u64 lo, u64 hi) { return sub32(gl_mad_eps((u32)hi, lo), (u32)(hi >> 32)); }
-    __device__ __forceinline__ u64 mul(u64 a, u64 b) { u64 lo, hi; mul128(a, b, lo, hi); return red128(lo, hi); }
-    // a*b + c for any 64-bit a, b, c (cannot overflow 128 bits)
+    // 12 VALU instructions: six v_mad_u64_u32 form  a*b + c = lo + hi*2^64 + cy*2^96  (the mid column a0*b1 + a1*b0 keeps its
+    // carry-out cy as a lane mask instead of propagating it), one v_mov pairs the low words, then lo + hi0*eps - hi1 - cy
+    // where cy rides the borrow-in of the final subtraction.
+    __device__ __forceinline__ u64 mul(u64 a, u64 b) {
+        u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+        u64 P0 = (u64)a0 * b0;
+        u64 A2 = madd1((u32)(P0 >> 32), (u64)a0 * b1);                  // <= (2^32-1)^2 + 2^32-1: no overflow
+        u64 X, cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(X), "=s"(cy) : "v"(a1), "v"(b0), "v"(A2));
+        u64 A4 = madd1((u32)(X >> 32), (u64)a1 * b1);
+        u64 lo = (X << 32) | (u32)P0;
+        return sub32c(gl_mad_eps((u32)A4, lo), (u32)(A4 >> 32), cy);
+    }
+    // a*b + c for any 64-bit a, b, c (cannot overflow 128 bits): c's words join the first two columns
     __device__ __forceinline__ u64 mul_add(u64 a, u64 b, u64 c) {
-        u64 lo, hi; mul128(a, b, lo, hi);
-        u64 l2 = lo + c; hi += (l2 < lo);
-        return red128(l2, hi);
+        u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+        u64 P0 = madd1((u32)c, (u64)a0 * b0);
+        u64 A2 = madd1((u32)(c >> 32), madd1((u32)(P0 >> 32), (u64)a0 * b1));   // <= (2^32-1)^2 + 2(2^32-1) = 2^64-1
+        u64 X, cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(X), "=s"(cy) : "v"(a1), "v"(b0), "v"(A2));
+        u64 A4 = madd1((u32)(X >> 32), (u64)a1 * b1);
+        u64 lo = (X << 32) | (u32)P0;
+        return sub32c(gl_mad_eps((u32)A4, lo), (u32)(A4 >> 32), cy);
     }
     __device__ __forceinline__ u64 sbox(u64 x) {
         u64 x2 = mul(x, x), x3 = mul(x2, x), x4 = mul(x2, x2);
@@ -145,8 +196,10 @@ template <bool EXACT> struct core {
         u64 r2; bool b = __builtin_sub_overflow(r1, sub, &r2);
         return r2 - (b ? GL_EPS : 0ull);
     }
-// out[r] = sum_i s[(i+r)%12]*CIRC[i] + (r==0)*8*s[0],  CIRC = [17,15,41,16,2,28,13,13,39,18,34,20]; weak in, weak out
-    __device__ __forceinline__ void mds_layer(u64 s[12]) {
+// out[r] = sum_i s[(i+r)%12]*CIRC[i] + (r==0)*8*s[0] + k[r],  CIRC = [17,15,41,16,2,28,13,13,39,18,34,20]; weak in, weak out.
+// k = the constants the NEXT layer would add (wave-uniform, canonical; PSD_ZERO12 = none): their two words start the two
+// column sums as SGPR-pair addends of the first v_mad_u64_u32, so the constant layer costs no vector instruction.
+    __device__ __forceinline__ void mds_layer(u64 s[12], const u64 *__restrict__ k) {
         const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
         u32 lo[12], hi[12];
 #pragma unroll
@@ -154,33 +207,39 @@ template <bool EXACT> struct core {
 #pragma unroll
         for (int r = 0; r < 12; r++) {
             u64 al = 0, ah = 0;
+            { u64 kr = k[r]; al = (u32)kr; ah = kr >> 32; }
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 al += (u64)lo[(i + r) % 12] * C[i];
                 ah += (u64)hi[(i + r) % 12] * C[i];
             }
             if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }
-            // value = al + ah*2^32 with al, ah < 2^42:  low64 + high*2^64, high < 2^11  ->  low + high*eps, one eps repair
-            u64 low = al + (ah << 32);
-            u64 high = (ah >> 32) + (low < al);
-            s[r] = gl_mad_eps((u32)high, low);
+            // value = al + ah*2^32 with al, ah < 2^43:  low64 + high*2^64, high < 2^12  ->  low + high*eps, one eps repair
+            // (32-bit add into al's high word + carry into ah's high word: two instructions, no register-pair shuffling)
+            u32 th, cy;
+            th = __builtin_addc((u32)(al >> 32), (u32)ah, 0u, &cy);
+            u32 high = (u32)(ah >> 32) + cy;
+            s[r] = gl_mad_eps(high, ((u64)th << 32) | (u32)al);
         }
     }
 
-    __device__ __forceinline__ void full_rounds(u64 s[12], int first_round) {
+    // four full rounds starting at round `first_round`; `after` = constants of the layer that follows the fourth
+    __device__ __forceinline__ void full_rounds(u64 s[12], int first_round, const u64 *__restrict__ after) {
+        {
+            const u64 *rc = PSD_RC + 12 * first_round;
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = wadd_c(s[i], rc[i]);
+        }
 #pragma unroll 1
         for (int r = 0; r < 4; r++) {
-            const u64 *rc = PSD_RC + 12 * (first_round + r);
 #pragma unroll
-            for (int i = 0; i < 12; i++) s[i] = sbox(wadd_c(s[i], rc[i]));
-            mds_layer(s);
+            for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+            mds_layer(s, r < 3 ? PSD_RC + 12 * (first_round + r + 1) : after);
         }
     }
 
     __device__ __forceinline__ void partial_rounds(u64 s[12]) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = wadd_c(s[i], PSD_PR_FIRST[i]);
-        {   // s[1..] = PR_INIT * s[1..]
+        {   // (PSD_PR_FIRST was added by the MDS layer of the last full round)  s[1..] = PR_INIT * s[1..]
             u64 t[11];
 #pragma unroll
             for (int i = 0; i < 11; i++) {
@@ -208,9 +267,9 @@ template <bool EXACT> struct core {
 
     // any 64-bit representatives in; canonical out
     __device__ __forceinline__ void run(u64 s[12]) {
-        full_rounds(s, 0);
+        full_rounds(s, 0, PSD_PR_FIRST);
         partial_rounds(s);
-        full_rounds(s, 26);
+        full_rounds(s, 26, PSD_ZERO12);
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
     }
