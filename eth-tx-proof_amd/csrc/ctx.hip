@@ -82,6 +82,7 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
     c->device = device;
     { const char *e = getenv("ZK_FORCE_EXACT_REDO"); c->force_redo = (e && atoi(e)) ? 1 : 0; }
     { const char *e = getenv("ZK_QUOTIENT_JIT"); if (e) c->quotient_jit_mode = atoi(e); }
+    { const char *e = getenv("ZK_POSEIDON_MFMA"); if (e) c->poseidon_mfma = atoi(e); }
     { const char *e = getenv("ZK_QUOTIENT_JIT_MIN_LOG"); if (e) c->quotient_jit_min_log = atoi(e); }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {

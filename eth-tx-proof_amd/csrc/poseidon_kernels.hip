@@ -5,8 +5,15 @@
 //
 // Layout: one thread = one leaf.  Leaves are rows of a column-major matrix, so lane i reads element i of each
 // column: every global load is a fully coalesced 512-byte wave access.  The 12-word sponge state stays in VGPRs.
+//
+// Big launches (whole commits, the wide Merkle levels) run the matrix-core permutation of poseidon_mfma.cuh: one wave =
+// 64 leaves / parents in "pair layout" (lane (n, h) holds words 6h..6h+5 of leaves n and 32+n of the wave's 64), column
+// loads still walk consecutive leaves (256-byte runs per column and half-wave).  Everything else keeps the one-thread-per-
+// permutation kernels below.
+#include <mutex>
 #include "zk_internal.h"
 #include "poseidon_coop.cuh"
+#include "poseidon_mfma.cuh"
 
 // sponge over the columns of one leaf; returns the sticky word of psd::core<false> (0 for EXACT)
 template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_colmajor(const u64 *__restrict__ p, size_t stride, u32 n_cols, u64 s[12]) {
@@ -43,6 +50,96 @@ __global__ __launch_bounds__(256) void hash_leaves_colmajor_kernel(const u64 *__
     o[0] = make_ulonglong2(s[0], s[1]);
     o[1] = make_ulonglong2(s[2], s[3]);
 }
+
+// ---- matrix-core variants ------------------------------------------------------------------------------------------
+// sponge over the columns of the wave's 64 leaves (leaf0 = first of them); state left in pair layout
+template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_pair(const PsdmTables *__restrict__ T, const u64 *__restrict__ cols, size_t stride,
+                                                                      u32 n_cols, size_t leaf0, u32 lane, const psdm_v4i *lds, u64 (&s)[2][6]) {
+    psdm::perm<EXACT> pm; pm.init(T, lane, lds);
+    const u32 n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) s[c][i] = 0;
+    for (u32 c0 = 0; c0 < n_cols; c0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const u32 w = 6 * h + i;                       // sponge word held in register i of this lane half
+            if (w < 8 && c0 + w < n_cols) {
+                const u64 *p = cols + (size_t)(c0 + w) * stride + leaf0 + n;
+                s[0][i] = p[0]; s[1][i] = p[32];
+            }
+        }
+        pm.run(s);
+    }
+    return pm.pc.fl;
+}
+__global__ __launch_bounds__(256, 2) void hash_leaves_colmajor_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ cols, size_t stride,
+                                                                          u32 n_cols, size_t n_leaves, u64 *__restrict__ out, u64 force_redo) {
+    const u32 lane = threadIdx.x & 63;
+    const size_t leaf0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(size_t)63;     // n_leaves is a multiple of 256
+    __shared__ psdm_v4i shA[PSDM_LDS_V4];
+    psdm::lds_fill(T, shA); __syncthreads();
+    u64 s[2][6];
+    if (leaf_sponge_pair<false>(T, cols, stride, n_cols, leaf0, lane, shA, s) | force_redo)
+        leaf_sponge_pair<true>(T, cols, stride, n_cols, leaf0, lane, shA, s);      // a skipped rare repair somewhere in this wave: redo exactly
+    if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            ulonglong2 *o = (ulonglong2 *)(out + 4 * (leaf0 + 32 * c + lane));
+            o[0] = make_ulonglong2(s[c][0], s[c][1]);
+            o[1] = make_ulonglong2(s[c][2], s[c][3]);
+        }
+    }
+}
+template <bool EXACT> __device__ __forceinline__ u64 two_to_one_pair(const PsdmTables *__restrict__ T, const u64 *__restrict__ child, size_t parent0,
+                                                                     u32 lane, const psdm_v4i *lds, u64 (&s)[2][6]) {
+    psdm::perm<EXACT> pm; pm.init(T, lane, lds);
+    const u32 n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const u64 *p = child + 8 * (parent0 + 32 * c + n);
+        if (h == 0) {
+            const ulonglong2 a = ((const ulonglong2 *)p)[0], b = ((const ulonglong2 *)p)[1], d = ((const ulonglong2 *)p)[2];
+            s[c][0] = a.x; s[c][1] = a.y; s[c][2] = b.x; s[c][3] = b.y; s[c][4] = d.x; s[c][5] = d.y;
+        } else {
+            const ulonglong2 e = ((const ulonglong2 *)p)[3];
+            s[c][0] = e.x; s[c][1] = e.y; s[c][2] = 0; s[c][3] = 0; s[c][4] = 0; s[c][5] = 0;
+        }
+    }
+    pm.run(s);
+    return pm.pc.fl;
+}
+__global__ __launch_bounds__(256, 2) void merkle_level_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ child, u64 *__restrict__ parent,
+                                                                  size_t n_parents, u64 force_redo) {
+    const u32 lane = threadIdx.x & 63;
+    const size_t parent0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(size_t)63;   // n_parents is a multiple of 256
+    __shared__ psdm_v4i shA[PSDM_LDS_V4];
+    psdm::lds_fill(T, shA); __syncthreads();
+    u64 s[2][6];
+    if (two_to_one_pair<false>(T, child, parent0, lane, shA, s) | force_redo) two_to_one_pair<true>(T, child, parent0, lane, shA, s);
+    if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            ulonglong2 *o = (ulonglong2 *)(parent + 4 * (parent0 + 32 * c + lane));
+            o[0] = make_ulonglong2(s[c][0], s[c][1]);
+            o[1] = make_ulonglong2(s[c][2], s[c][3]);
+        }
+    }
+}
+// device copy of the matrix-core tables of this context (built on the host once per process)
+static const PsdmTables *psdm_tables(zk_ctx *ctx) {
+    if (ctx->d_psdm) return (const PsdmTables *)ctx->d_psdm;
+    static PsdmTables host_tab;
+    static std::once_flag once;
+    std::call_once(once, [] { psdm_host::build(host_tab); });
+    void *d = ctx->alloc(sizeof(PsdmTables));
+    if (!d) return nullptr;
+    if (hipMemcpyAsync(d, &host_tab, sizeof(PsdmTables), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->release(d); return nullptr; }
+    ctx->d_psdm = d;
+    return (const PsdmTables *)d;
+}
+#define PSDM_MIN_UNITS 16384    // below this a launch no longer fills the chip two waves per SIMD deep: keep thread-per-unit
 
 template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_rowmajor(const u64 *__restrict__ p, u32 leaf_len, int canon, u64 s[12]) {
     psd::core<EXACT> pc; pc.fl = 0;
@@ -161,6 +258,13 @@ __global__ void digests_layout_kernel(const u64 *levels, size_t n_leaves, u32 n_
 static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uint32_t n_cols, size_t n_leaves, u64 *digests) {
+    if (ctx->poseidon_mfma && n_cols > 4 && n_leaves >= PSDM_MIN_UNITS && n_leaves % 256 == 0) {
+        const PsdmTables *T = psdm_tables(ctx);
+        if (!T) return ZK_ERR_OOM;
+        ZK_LAUNCH(ctx, "poseidon_leaf_hash", hash_leaves_colmajor_mfma_kernel, dim3((unsigned)(n_leaves / 256)), dim3(256), 0, T, cols, stride, n_cols,
+                  n_leaves, digests, ctx->force_redo);
+        return ZK_OK;
+    }
     ZK_LAUNCH(ctx, "poseidon_leaf_hash", hash_leaves_colmajor_kernel, grid1(n_leaves), dim3(256), 0, cols, stride, n_cols, n_leaves, digests, ctx->force_redo);
     return ZK_OK;
 }
@@ -173,7 +277,12 @@ int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap
     u64 *cur = levels;
     while (cnt > ((size_t)1 << cap_height)) {
         u64 *nxt = cur + 4 * cnt;
-        if (cnt / 2 <= 16384)
+        if (ctx->poseidon_mfma && cnt / 2 >= PSDM_MIN_UNITS && (cnt / 2) % 256 == 0) {
+            const PsdmTables *T = psdm_tables(ctx);
+            if (!T) return ZK_ERR_OOM;
+            ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_mfma_kernel, dim3((unsigned)(cnt / 2 / 256)), dim3(256), 0, T, (const u64 *)cur, nxt, cnt / 2,
+                      ctx->force_redo);
+        } else if (cnt / 2 <= 16384)
             ZK_LAUNCH(ctx, "poseidon_merkle_level_coop", merkle_level_coop_kernel, grid1(cnt / 2 * 16), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
         else
             ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_kernel, grid1(cnt / 2), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo);

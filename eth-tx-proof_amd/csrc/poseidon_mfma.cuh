@@ -1,0 +1,210 @@
+// Poseidon-Goldilocks permutation with its linear layers on the gfx950 matrix cores (v_mfma_i32_32x32x32_i8).
+// Same function as psd::core::run (poseidon.cuh; plonky2 0.2.2 hash/poseidon.rs `Poseidon::poseidon`, crate pinned at
+// /root/reference/Cargo.lock:3441-3443), bit for bit; tables and layout: poseidon_mfma_tables.h.
+//
+// One wave = 64 permutations in "pair layout": lane (n = l&31, h = l>>5) holds words 6h..6h+5 of permutations n and 32+n.
+//   * s-boxes: 12 per lane per full round, exactly as in the one-thread-per-permutation kernel (psd::core products);
+//   * MDS (+ next round constants): 18 matrix-core instructions per wave and layer, operands straight from the state
+//     registers (bytes XOR 0x80), results recombined from eight 25-bit limb sums per word with 13 vector instructions --
+//     against 24 multiply-adds + 5 per word on the vector ALU;
+//   * the 22 partial rounds: everything that is linear in the state is two matrix products (E = what the untouched words
+//     contribute to each s-box input, and the exit map), and only the s-box chain with its triangular feedback
+//     x_{q+1} = E[q] + sum_{j<=q} PR_D[q][j] y_j runs on the vector ALU, one permutation per lane (two v_permlane32_swap
+//     exchanges per word in and out).
+// The rare-repair protocol of psd::core<false> (sticky word, exact redo) carries over unchanged: the matrix products and the
+// recombination are exact.
+#pragma once
+#include "poseidon.cuh"
+#include "poseidon_mfma_tables.h"
+
+typedef int psdm_v4i __attribute__((ext_vector_type(4)));
+typedef int psdm_v16i __attribute__((ext_vector_type(16)));
+
+#define PSDM_LDS_V4 (9 * 64)       // the MDS operand tiles, one 16-byte fragment per (tile, k-step, lane)
+
+namespace psdm {
+
+__device__ __forceinline__ psdm_v4i ld4(const void *p);
+// every workgroup: all threads call this on its `__shared__ psdm_v4i sh[PSDM_LDS_V4]`, then __syncthreads().  The MDS operand is
+// used 8 x 18 times per permutation: reading it from LDS costs no vector registers (36 if held) and no L1 traffic.
+__device__ __forceinline__ void lds_fill(const PsdmTables *T, psdm_v4i *sh) {
+    const psdm_v4i *src = (const psdm_v4i *)&T->A_mds[0][0][0][0];
+    for (u32 i = threadIdx.x; i < PSDM_LDS_V4; i += blockDim.x) sh[i] = src[i];
+}
+
+__device__ __forceinline__ psdm_v4i ld4(const void *p) { return *(const psdm_v4i *)p; }
+__device__ __forceinline__ psdm_v16i ld16(const int32_t *p) {
+    psdm_v16i v;
+    psdm_v4i a = ld4(p), b = ld4(p + 4), c = ld4(p + 8), d = ld4(p + 12);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    v[8] = c[0]; v[9] = c[1]; v[10] = c[2]; v[11] = c[3]; v[12] = d[0]; v[13] = d[1]; v[14] = d[2]; v[15] = d[3];
+    return v;
+}
+// sixteen operand bytes of one k-step: two state words, every byte XOR 0x80 (u - 128 as a signed byte)
+__device__ __forceinline__ psdm_v4i bfrag(u64 w0, u64 w1) {
+    psdm_v4i b;
+    b[0] = (int)((u32)w0 ^ 0x80808080u); b[1] = (int)((u32)(w0 >> 32) ^ 0x80808080u);
+    b[2] = (int)((u32)w1 ^ 0x80808080u); b[3] = (int)((u32)(w1 >> 32) ^ 0x80808080u);
+    return b;
+}
+// sum_a u_a 2^(8a), u_a < 2^25, as a weak residue: two 4-term multiply-add chains (low and high half), then
+// AL + AH*2^32 = low64 + high*2^64 with high < 2^27 -> low + high*eps.  The multipliers 1, 2^8, 2^16, 2^24 are handed over as
+// opaque wave-uniform values (struct rk): hipcc then emits one v_mad_u64_u32 per term, whereas with visible constants it
+// builds zero-extend + 64-bit shift + add (three instructions per term).  They stay compiler-generated instructions on
+// purpose: the first reader of a matrix-core result must be visible to the hazard recognizer (an inline-asm reader is not).
+struct rk {
+    u32 k0, k8, k16, k24;
+    __device__ __forceinline__ void init() {
+        k0 = 1u; k8 = 1u << 8; k16 = 1u << 16; k24 = 1u << 24;
+        asm("" : "+s"(k0), "+s"(k8), "+s"(k16), "+s"(k24));
+    }
+};
+__device__ __forceinline__ u64 recombine(const rk &K, u32 u0, u32 u1, u32 u2, u32 u3, u32 u4, u32 u5, u32 u6, u32 u7) {
+    u64 AL = (u64)u3 * K.k24; AL += (u64)u2 * K.k16; AL += (u64)u1 * K.k8; AL += (u64)u0 * K.k0;
+    u64 AH = (u64)u7 * K.k24; AH += (u64)u6 * K.k16; AH += (u64)u5 * K.k8; AH += (u64)u4 * K.k0;
+    u32 th, cy;
+    th = __builtin_addc((u32)(AL >> 32), (u32)AH, 0u, &cy);
+    u32 high = (u32)(AH >> 32) + cy;
+    return gl_mad_eps(high, ((u64)th << 32) | (u32)AL);
+}
+__device__ __forceinline__ void recombine2(const rk &K, const psdm_v16i &acc, u64 &o0, u64 &o1) {
+    o0 = recombine(K, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+    o1 = recombine(K, acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
+}
+__device__ __forceinline__ void swap32(u64 &vdst, u64 &src) {   // vdst lanes 32..63 <-> src lanes 0..31
+    auto lo = __builtin_amdgcn_permlane32_swap((u32)vdst, (u32)src, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((u32)(vdst >> 32), (u32)(src >> 32), false, false);
+    vdst = ((u64)hi[0] << 32) | lo[0]; src = ((u64)hi[1] << 32) | lo[1];
+}
+
+template <bool EXACT> struct perm {
+    psd::core<EXACT> pc;
+    const PsdmTables *__restrict__ T;
+    u32 lane;
+    rk K;
+    const psdm_v4i *Alds;      // the workgroup's LDS copy of A_mds (9 KiB), see lds_fill
+
+    __device__ __forceinline__ void init(const PsdmTables *tab, u32 lane_, const psdm_v4i *lds) { T = tab; lane = lane_; pc.fl = 0; K.init(); Alds = lds; }
+
+    // s <- MDS * s + constants of layer `layer`
+    __device__ __forceinline__ void mds(u64 (&s)[2][6], int layer) {
+        psdm_v4i b[2][3];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) b[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const psdm_v16i cin = ld16(&T->Cin_mds[layer][t][lane >> 5][0]);
+            const psdm_v4i a0 = Alds[(3 * t + 0) * 64 + lane], a1 = Alds[(3 * t + 1) * 64 + lane], a2 = Alds[(3 * t + 2) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                psdm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[c][0], cin, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[c][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b[c][2], acc, 0, 0, 0);
+                recombine2(K, acc, s[c][2 * t], s[c][2 * t + 1]);
+            }
+        }
+    }
+    __device__ __forceinline__ void full_rounds(u64 (&s)[2][6], int layer0) {
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int i = 0; i < 6; i++) s[c][i] = pc.sbox(s[c][i]);
+            mds(s, layer0 + r);
+        }
+    }
+
+    __device__ __forceinline__ void partial_rounds(u64 (&s)[2][6]) {
+        // ---- E = G1 * s for both column tiles, in pair layout: E[c][o] = E_(c,n)[11h + o]
+        u64 E[2][12];
+        {
+            psdm_v4i b[2][3];
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) b[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                const psdm_v16i cin = ld16(&T->Cin_E[t][lane >> 5][0]);
+                const psdm_v4i a0 = ld4(&T->A_E[t][0][lane][0]), a1 = ld4(&T->A_E[t][1][lane][0]), a2 = ld4(&T->A_E[t][2][lane][0]);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    psdm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[c][0], cin, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[c][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b[c][2], acc, 0, 0, 0);
+                    recombine2(K, acc, E[c][2 * t], E[c][2 * t + 1]);
+                }
+            }
+        }
+        // ---- to one permutation per lane: lane (n, h) runs permutation (c = h, n)
+        u64 Eo[22];
+#pragma unroll
+        for (int o = 0; o < 11; o++) { u64 y = E[0][o], x = E[1][o]; swap32(y, x); Eo[o] = y; Eo[11 + o] = x; }
+        u64 x;
+        { u64 d = s[0][0], w = s[1][0]; swap32(d, w); x = d; }
+        // ---- s-box chain: y_q = x_q^7 + K[q];  x_{q+1} = E[q] + 25 y_q + sum_{j<q} PR_D[q][j] y_j   (x_22 comes out of G2)
+        u64 y[24];
+        // (the 210 wave-uniform constants PSD_PR_D are scalar loads that hipcc hoists out of the caller's loop and parks in
+        // VGPR lanes, one v_readlane per use; measured faster than LDS broadcast reads or loads kept inside the serial chain)
+        const u64 *Dm = PSD_PR_D, *Kc = PSD_PR_K;
+#pragma unroll
+        for (int q = 0; q < 22; q++) {
+            y[q] = psd::wadd_c(pc.sbox(x), Kc[q]);
+            if (q == 21) break;
+            psd::acc3 a; a.init();
+            a.c0 = (u64)(u32)Eo[q] + (u64)(u32)y[q] * (u32)PSD_M00;
+            a.c1 = (Eo[q] >> 32) + (y[q] >> 32) * (u32)PSD_M00;
+#pragma unroll
+            for (int j = 0; j < q; j++) a.mac_s(Dm[22 * q + j], y[j]);
+            x = pc.reduce(a);
+        }
+        y[22] = 0; y[23] = 0;
+        // ---- back to pair layout: Y[0][sl] = y_(0,n)[11h + sl], Y[1][sl] = y_(1,n)[11h + sl]
+        u64 Y[2][12];
+#pragma unroll
+        for (int sl = 0; sl < 11; sl++) { u64 lo = y[sl], hi = y[11 + sl]; swap32(lo, hi); Y[0][sl] = lo; Y[1][sl] = hi; }
+        Y[0][11] = 0; Y[1][11] = 0;
+        // ---- exit map G2 (K = 12 state words + 2 x 12 slots of y), + RC[26]
+        psdm_v4i bs[2][3];                 // the state enters through its operand bytes only: s can take the results
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) bs[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const psdm_v16i cin = ld16(&T->Cin_G2[t][lane >> 5][0]);
+            psdm_v16i acc0 = cin, acc1 = cin;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const psdm_v4i a = ld4(&T->A_G2[t][k][lane][0]);
+                const psdm_v4i b0 = k < 3 ? bs[0][k] : bfrag(Y[0][2 * (k - 3)], Y[0][2 * (k - 3) + 1]);
+                const psdm_v4i b1 = k < 3 ? bs[1][k] : bfrag(Y[1][2 * (k - 3)], Y[1][2 * (k - 3) + 1]);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc1, 0, 0, 0);
+            }
+            recombine2(K, acc0, s[0][2 * t], s[0][2 * t + 1]);
+            recombine2(K, acc1, s[1][2 * t], s[1][2 * t + 1]);
+        }
+    }
+
+    // any 64-bit representatives in, canonical out
+    __device__ __forceinline__ void run(u64 (&s)[2][6]) {
+        {
+            const u64 *rc0 = T->RC_first + 6 * (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { const u64 k = rc0[i]; s[0][i] = psd::wadd_c(s[0][i], k); s[1][i] = psd::wadd_c(s[1][i], k); }
+        }
+        full_rounds(s, 0);
+        partial_rounds(s);
+        full_rounds(s, 4);
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 6; i++) s[c][i] = gl_canon(s[c][i]);
+    }
+};
+
+}  // namespace psdm

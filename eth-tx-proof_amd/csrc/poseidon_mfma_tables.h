@@ -1,0 +1,163 @@
+// Host-side builder of the constant tables of the matrix-core Poseidon permutation (poseidon_mfma.cuh).
+//
+// The linear layers of Poseidon-Goldilocks (plonky2 0.2.2 hash/poseidon.rs: mds_layer, partial_first_constant_layer,
+// mds_partial_layer_init, mds_partial_layer_fast; crate pinned at /root/reference/Cargo.lock:3441-3443) are
+// products of a CONSTANT matrix over F_p with the state vectors of many independent permutations: a dense contraction.  It is
+// done exactly on the i8 matrix cores by splitting both sides into bytes:
+//     out[W] = sum_wi M[W][wi] * x[wi],   x[wi] = sum_b u_b 2^(8b)   (u_b = bytes of the 64-bit word)
+//            = sum_a 2^(8a) * sum_(wi,b) digit_a( M[W][wi] * 2^(8b) mod p ) * u_b
+// where digit_a(.) are the eight signed base-256 digits (-128..127) of the representative of least absolute value.  The
+// matrix-core operands are signed bytes, so u_b enters as s_b = u_b - 128 (one XOR with 0x80 per byte) and the accumulator
+// starts at 128 * rowsum, plus an offset that keeps it non-negative, plus the matching byte of the additive constant of the
+// layer (round constants), so that constant layers cost nothing.
+//
+// Lane maps of v_mfma_i32_32x32x32_i8 (checked with exact integer data by tools/mfma_probe.hip): A: lane l holds
+// A[row l&31][(l>>5, j)], j = 0..15; B: lane l holds B[(l>>5, j)][col l&31]; D: register r of lane l is
+// D[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31].
+//
+// State layout ("pair layout"): a wave holds 64 permutations P = 32c + n; lane l = (n = l&31, h = l>>5) holds words
+// 6h .. 6h+5 of permutations (c = 0, n) and (c = 1, n).  K index (k-step ks, lane half h, byte j) = byte j&7 of word
+// 6h + 2ks + (j>>3); output row (tile T, r = 4t + i on lane half h') = limb 4(t&1) + i of output slot 2T + (t>>1) of that
+// half: both operands of every layer come straight from, and land straight in, the state registers.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "gl64.cuh"
+
+struct PsdmTables {
+    int8_t A_mds[3][3][64][16];
+    int32_t Cin_mds[8][3][2][16];      // [layer][tile][lane half][register]; layer L: next-layer constants RC[L+1] (L<3), PR_FIRST (3), RC[27+L-4] (4..6), none (7)
+    int8_t A_E[6][3][64][16];          // E[e] = <vhat_e, PR_INIT * s[1..]>, e = 11h' + slot
+    int32_t Cin_E[6][2][16];
+    int8_t A_G2[3][9][64][16];         // exit of the partial rounds: K = 12 state words + 22 (24 slots) s-box outputs
+    int32_t Cin_G2[3][2][16];          // + RC[26]
+    uint64_t RC_first[12];
+};
+
+namespace psdm_host {
+#undef PSD_CONST
+#define PSD_CONST static const
+#include "poseidon_constants.inc"
+
+static const uint32_t OFF_LOG = 24;    // accumulators lie in (-2^23.3, 2^23.3) for K <= 288 signed-byte products
+
+// eight signed base-256 digits (-128..127) of a representative of c (mod p).  Eight such digits cover
+// [-128 (2^64-1)/255, 127 (2^64-1)/255]: c itself up to 0x7F7F7F7F7F7F7F7F, c - p above (c - p > -128 (2^64-1)/255 there).
+static inline void signed_digits(u64 c, int8_t d[8]) {
+    __int128 sv = (c <= 0x7F7F7F7F7F7F7F7FULL) ? (__int128)c : (__int128)c - (__int128)GL_P;
+    for (int a = 0; a < 8; a++) {
+        int low = (int)(sv & 0xFF);
+        if (low >= 128) low -= 256;
+        d[a] = (int8_t)low;
+        sv = (sv - low) >> 8;                           // exact: sv - low is a multiple of 256
+    }
+    if (sv != 0) abort();
+}
+
+struct RowSpec { bool live; int word; int limb; };
+// row (tile T, index rho = 8t + 4h' + i)
+static inline void row_of(int T, int rho, int &hp, int &slot, int &limb) {
+    int t = rho >> 3, i = rho & 3; hp = (rho >> 2) & 1;
+    slot = 2 * T + (t >> 1); limb = 4 * (t & 1) + i;
+}
+// lane l, register r of the accumulator of tile T  ->  row index in the tile
+static inline int rho_of(int l, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (l >> 5); }
+
+// Generic filler: `coef(out_id, kword)` gives the matrix entry (mod p) of output out_id (what `out_of(hp, slot)` returns, or -1
+// for a dead row) against K-word kword (what `kword_of(ks, h, wsel)` returns, or -1 for padding); addc(out_id) the additive
+// constant.
+template <class OutOf, class KWordOf, class Coef, class AddC>
+static void fill(int n_tiles, int n_ksteps, int8_t *A /*[T][ks][64][16]*/, int32_t *Cin /*[T][2][16]*/, OutOf out_of, KWordOf kword_of,
+                 Coef coef, AddC addc) {
+    const u64 ONES = 0x0101010101010101ULL % GL_P;
+    const u64 offc = gl_mul(((u64)1 << OFF_LOG) % GL_P, ONES);
+    for (int T = 0; T < n_tiles; T++) {
+        long rowsum[32];
+        for (int m = 0; m < 32; m++) rowsum[m] = 0;
+        for (int ks = 0; ks < n_ksteps; ks++)
+            for (int l = 0; l < 64; l++) {
+                int m = l & 31, h = l >> 5, hp, slot, limb;
+                row_of(T, m, hp, slot, limb);
+                int out_id = out_of(hp, slot);
+                int8_t *dst = A + (((size_t)T * n_ksteps + ks) * 64 + l) * 16;
+                for (int j = 0; j < 16; j++) {
+                    int kw = kword_of(ks, h, j >> 3), b = j & 7;
+                    int8_t v = 0;
+                    if (out_id >= 0 && kw >= 0) {
+                        u64 c = gl_mul(coef(out_id, kw), gl_pow(2, 8 * b));
+                        int8_t d[8]; signed_digits(c, d);
+                        v = d[limb];
+                    }
+                    dst[j] = v;
+                    rowsum[m] += v;
+                }
+            }
+        for (int hh = 0; hh < 2; hh++)                      // the accumulator start depends on the row only: one copy per lane half
+            for (int r = 0; r < 16; r++) {
+                int rho = rho_of(32 * hh, r), hp, slot, limb;
+                row_of(T, rho, hp, slot, limb);
+                int out_id = out_of(hp, slot);
+                int32_t v = (int32_t)1 << OFF_LOG;
+                if (out_id >= 0) {
+                    u64 kk = gl_sub(addc(out_id) % GL_P, offc);
+                    v += (int32_t)(128 * rowsum[rho]) + (int32_t)((kk >> (8 * limb)) & 0xFF);
+                }
+                Cin[((size_t)T * 2 + hh) * 16 + r] = v;
+            }
+    }
+}
+
+static inline u64 mds_entry(int W, int wi) {
+    static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    return C[((wi - W) % 12 + 12) % 12] + ((W == 0 && wi == 0) ? 8 : 0);
+}
+
+static void build(PsdmTables &t) {
+    memset(&t, 0, sizeof t);
+    auto state_kword = [](int ks, int h, int wsel) { return ks < 3 ? 6 * h + 2 * ks + wsel : -1; };
+    auto word_out = [](int hp, int slot) { return slot < 6 ? 6 * hp + slot : -1; };
+    // ---- MDS (+ the constants of the layer that follows)
+    for (int L = 0; L < 8; L++) {
+        const u64 *nxt = nullptr;
+        if (L < 3) nxt = PSD_RC + 12 * (L + 1);
+        else if (L == 3) nxt = PSD_PR_FIRST;
+        else if (L < 7) nxt = PSD_RC + 12 * (26 + (L - 4) + 1);
+        static int8_t Atmp[3][3][64][16];
+        fill(3, 3, L == 0 ? &t.A_mds[0][0][0][0] : &Atmp[0][0][0][0], &t.Cin_mds[L][0][0][0], word_out, state_kword,
+             [](int W, int wi) { return mds_entry(W, wi); }, [&](int W) { return nxt ? nxt[W] : (u64)0; });
+    }
+    // ---- G1: E[e] = sum_j (sum_i vhat_e[i] * PR_INIT[11 i + j]) * s[1 + j]
+    static u64 G1[22][12];
+    for (int e = 0; e < 22; e++) {
+        G1[e][0] = 0;
+        for (int j = 0; j < 11; j++) {
+            u64 acc = 0;
+            for (int i = 0; i < 11; i++) acc = gl_add(acc, gl_mul(PSD_PR_VHAT[11 * e + i], PSD_PR_INIT[11 * i + j]));
+            G1[e][1 + j] = acc;
+        }
+    }
+    fill(6, 3, &t.A_E[0][0][0][0], &t.Cin_E[0][0][0], [](int hp, int slot) { return slot < 11 ? 11 * hp + slot : -1; }, state_kword,
+         [&](int e, int wi) { return G1[e][wi]; }, [](int) { return (u64)0; });
+    // ---- G2: new s[0] = E[21] + sum_q PR_D[21][q] y_q;  new s[1+i] = (PR_INIT s[1..])[i] + sum_q PR_W[q][i] y_q;  + RC[26]
+    // K words: 0..11 = state at the entry of the partial rounds, 12 + q = y_q
+    auto g2_kword = [](int ks, int h, int wsel) {
+        if (ks < 3) return 6 * h + 2 * ks + wsel;
+        int sl = 2 * (ks - 3) + wsel;
+        return sl < 11 ? 12 + 11 * h + sl : -1;
+    };
+    fill(3, 9, &t.A_G2[0][0][0][0], &t.Cin_G2[0][0][0], word_out, g2_kword,
+         [&](int W, int kw) -> u64 {
+             if (kw < 12) {
+                 if (W == 0) return G1[21][kw];
+                 return kw == 0 ? 0 : PSD_PR_INIT[11 * (W - 1) + (kw - 1)];
+             }
+             int q = kw - 12;
+             return W == 0 ? PSD_PR_D[22 * 21 + q] : PSD_PR_W[11 * q + (W - 1)];
+         },
+         [](int W) { return PSD_RC[12 * 26 + W]; });
+    for (int i = 0; i < 12; i++) t.RC_first[i] = PSD_RC[i];
+}
+
+}  // namespace psdm_host

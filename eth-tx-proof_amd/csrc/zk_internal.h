@@ -27,6 +27,9 @@ struct zk_ctx {
     // constraint-program JIT (prover_quotient_jit.hip): env ZK_QUOTIENT_JIT = 0 off / 1 tables with >= 2^ZK_QUOTIENT_JIT_MIN_LOG
     // coset points (default 17) / 2 always; read when the context is created
     int quotient_jit_mode = 1, quotient_jit_min_log = 17;
+    // matrix-core Poseidon for big leaf / Merkle-level launches (poseidon_mfma.cuh): env ZK_POSEIDON_MFMA = 0 turns it off
+    int poseidon_mfma = 1;
+    void *d_psdm = nullptr;                                        // device copy of PsdmTables (built at first use)
     std::string last_error;
     // caching device allocator (stream-ordered reuse on the ctx stream)
     std::multimap<size_t, void *> free_blocks;
