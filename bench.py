@@ -155,8 +155,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dbg = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if os.environ.get("ZK_BENCH_DEBUG") else (lambda m: None)
     for _ in range(args.warmup):
         step()
+        fence()
+        dbg("warmup step done")
     # One untimed unit ALONE on the GPU with the profiler on: which kernel dominates is decided from these solo
     # durations (when several streams share the chip, a kernel's elapsed time also contains time spent waiting for CUs).
     ctxs[0].profile(True)
@@ -165,6 +168,7 @@ def main():
     if errors:
         raise errors[0]
     solo = ctxs[0].profile_report()
+    dbg("solo profiled unit done")
     for c in ctxs:                       # every stream is profiled over the timed region (same population rocprofv3 sees)
         c.profile(True)
         c.profile_reset()
@@ -174,6 +178,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    dbg("timed steps done")
     for c in ctxs:
         c.profile(False)
     if world > 1:

@@ -2,6 +2,7 @@
 // Boundary: include/zkgl.h "context" group.  One ctx = one device + one HIP stream = one worker thread of the
 // reference's runtime (paladin `--num-workers N`, /root/reference/README.md:60-63).
 #include <stdlib.h>
+#include <string.h>
 #include "zk_internal.h"
 
 void *zk_ctx::alloc(size_t bytes) {
@@ -14,6 +15,26 @@ void *zk_ctx::alloc(size_t bytes) {
         return p;
     }
     void *p = nullptr;
+    if (efence) {
+        // debug allocator (env ZK_ALLOC_EFENCE=1): every block ends exactly at the end of its own mapping and the next
+        // virtual page is reserved but unmapped, so any read or write past the end of a buffer faults at the kernel that does it
+        // (use with ZK_SYNC_LAUNCH=1 to get its name).  Blocks are never returned to the driver.
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !gran) gran = 2u << 20;
+        size_t mapped = (bytes + gran - 1) / gran * gran;
+        void *va = nullptr; hipMemGenericAllocationHandle_t h;
+        hipMemAccessDesc ad = {}; ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemAddressReserve(&va, mapped + gran, gran, nullptr, 0) != hipSuccess || hipMemCreate(&h, mapped, &prop, 0) != hipSuccess ||
+            hipMemMap(va, mapped, 0, h, 0) != hipSuccess || hipMemSetAccess(va, mapped, &ad, 1) != hipSuccess) {
+            last_error = "efence allocation failed"; return nullptr;
+        }
+        p = (char *)va + (mapped - bytes);
+        block_size[p] = bytes; bytes_allocated += bytes;
+        if (sync_launch) fprintf(stderr, "[zk %p] efence %zu at %p .. %p\n", (void *)this, bytes, p, (void *)((char *)p + bytes));
+        return p;
+    }
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         // give cached blocks back to the driver and retry once
@@ -24,7 +45,40 @@ void *zk_ctx::alloc(size_t bytes) {
     }
     block_size[p] = bytes;
     bytes_allocated += bytes;
+    if (sync_launch) fprintf(stderr, "[zk] hipMalloc %zu at %p .. %p\n", bytes, p, (void *)((char *)p + bytes));
     return p;
+}
+
+const void *zk_ctx::stage_pinned(const void *src, size_t bytes) {
+    if (!h_stage) {
+        if (hipHostMalloc((void **)&h_stage, (size_t)1 << 20, hipHostMallocDefault) != hipSuccess) { h_stage = nullptr; return nullptr; }
+        h_stage_cap = (size_t)1 << 20; h_stage_used = 0;
+    }
+    size_t need = (bytes + 63) & ~(size_t)63;
+    if (h_stage_used + need > h_stage_cap) return nullptr;
+    char *p = h_stage + h_stage_used;
+    h_stage_used += need;
+    memcpy(p, src, bytes);
+    return p;
+}
+void *zk_ctx::pinned_out(size_t bytes) {
+    if (h_out_cap >= bytes) return h_out;
+    if (h_out) { hipStreamSynchronize(stream); hipHostFree(h_out); h_out = nullptr; h_out_cap = 0; }
+    size_t cap = (bytes + ((size_t)1 << 16)) & ~(((size_t)1 << 16) - 1);
+    if (hipHostMalloc((void **)&h_out, cap, hipHostMallocDefault) != hipSuccess) { h_out = nullptr; return nullptr; }
+    h_out_cap = cap;
+    return h_out;
+}
+int32_t zk_ctx::upload_small(void *d_dst, const void *src, size_t bytes) {
+    if (!bytes) return ZK_OK;
+    if (const void *p = stage_pinned(src, bytes)) {
+        if (hipMemcpyAsync(d_dst, p, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return fail(ZK_ERR_HIP, "upload_small: hipMemcpyAsync");
+        return ZK_OK;
+    }
+    // staging full: copy straight from the caller's memory and wait for it
+    if (hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+        return fail(ZK_ERR_HIP, "upload_small: synchronous copy");
+    return ZK_OK;
 }
 
 void zk_ctx::release(void *p) {
@@ -83,6 +137,8 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
     { const char *e = getenv("ZK_FORCE_EXACT_REDO"); c->force_redo = (e && atoi(e)) ? 1 : 0; }
     { const char *e = getenv("ZK_QUOTIENT_JIT"); if (e) c->quotient_jit_mode = atoi(e); }
     { const char *e = getenv("ZK_POSEIDON_MFMA"); if (e) c->poseidon_mfma = atoi(e); }
+    { const char *e = getenv("ZK_SYNC_LAUNCH"); if (e) c->sync_launch = atoi(e); }
+    { const char *e = getenv("ZK_ALLOC_EFENCE"); if (e) c->efence = atoi(e); }
     { const char *e = getenv("ZK_QUOTIENT_JIT_MIN_LOG"); if (e) c->quotient_jit_min_log = atoi(e); }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -101,8 +157,10 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     hipStreamSynchronize(c->stream);
     c->prof_flush();
     for (auto e : c->event_pool) hipEventDestroy(e);
-    for (auto &kv : c->block_size) hipFree(kv.first);
+    if (!c->efence) for (auto &kv : c->block_size) hipFree(kv.first);
     hipFree(c->d_err);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_out) hipHostFree(c->h_out);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return ZK_OK;

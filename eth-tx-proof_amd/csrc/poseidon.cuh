@@ -84,7 +84,10 @@ struct acc3 {
     __device__ __forceinline__ void mac_s(u64 a /* wave-uniform */, u64 b) {
         u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
         u64 k0, k1, k2, k3;
+        // (leading s_nop 1: under SGPR pressure hipcc parks constants in VGPR lanes and restores them with v_readlane right
+        // before this block -- a vector write of an SGPR needs two wait states before a vector read, and hipcc cannot see into it)
         asm volatile(
+            "s_nop 1\n\t"
             "v_mad_u64_u32 %[c0], %[k0], %[a0], %[b0], %[c0]\n\t"
             "v_mad_u64_u32 %[c1], %[k1], %[a0], %[b1], %[c1]\n\t"
             "v_mad_u64_u32 %[c2], %[k2], %[a1], %[b1], %[c2]\n\t"
@@ -129,7 +132,10 @@ template <bool EXACT> struct core {
                 : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h), [c] "s"(cin));
             return (((u64)dh << 32) | dl) - (u64)m;
         } else {
-            asm("v_subb_co_u32 %[dl], %[k], %[rl], %[h], %[c]\n\t"
+            // (leading s_nop 0: cin may have been restored from a VGPR lane by v_readlane just before this block; with hipcc's own
+            // boundary state that makes the two wait states a vector-written SGPR needs before a vector read)
+            asm("s_nop 0\n\t"
+                "v_subb_co_u32 %[dl], %[k], %[rl], %[h], %[c]\n\t"
                 "s_nop 1\n\t"
                 "v_subbrev_co_u32 %[dh], %[k], 0, %[rh], %[k]\n\t"
                 : [dl] "=&v"(dl), [dh] "=&v"(dh), [k] "=&s"(k)

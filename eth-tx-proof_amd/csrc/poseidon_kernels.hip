@@ -127,17 +127,26 @@ __global__ __launch_bounds__(256, 2) void merkle_level_mfma_kernel(const PsdmTab
         }
     }
 }
-// device copy of the matrix-core tables of this context (built on the host once per process)
+// device copy of the matrix-core tables: built on the host once per process, one copy per device shared by all contexts,
+// uploaded with a blocking hipMemcpy under a lock (complete before any launch that uses it can be enqueued)
 static const PsdmTables *psdm_tables(zk_ctx *ctx) {
     if (ctx->d_psdm) return (const PsdmTables *)ctx->d_psdm;
     static PsdmTables host_tab;
-    static std::once_flag once;
-    std::call_once(once, [] { psdm_host::build(host_tab); });
-    void *d = ctx->alloc(sizeof(PsdmTables));
-    if (!d) return nullptr;
-    if (hipMemcpyAsync(d, &host_tab, sizeof(PsdmTables), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->release(d); return nullptr; }
-    ctx->d_psdm = d;
-    return (const PsdmTables *)d;
+    static std::mutex mu;
+    static bool built = false;
+    static void *dev_tab[64] = {nullptr};
+    std::lock_guard<std::mutex> lk(mu);
+    if (!built) { psdm_host::build(host_tab); built = true; }
+    if (ctx->device < 0 || ctx->device >= 64) return nullptr;
+    if (!dev_tab[ctx->device]) {
+        void *d = nullptr;
+        if (hipMalloc(&d, sizeof(PsdmTables)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, &host_tab, sizeof(PsdmTables), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+        dev_tab[ctx->device] = d;
+        if (ctx->sync_launch) fprintf(stderr, "[zk] PsdmTables at %p .. %p\n", d, (void *)((char *)d + sizeof(PsdmTables)));
+    }
+    ctx->d_psdm = dev_tab[ctx->device];
+    return (const PsdmTables *)ctx->d_psdm;
 }
 #define PSDM_MIN_UNITS 16384    // below this a launch no longer fills the chip two waves per SIMD deep: keep thread-per-unit
 
@@ -258,7 +267,7 @@ __global__ void digests_layout_kernel(const u64 *levels, size_t n_leaves, u32 n_
 static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uint32_t n_cols, size_t n_leaves, u64 *digests) {
-    if (ctx->poseidon_mfma && n_cols > 4 && n_leaves >= PSDM_MIN_UNITS && n_leaves % 256 == 0) {
+    if ((ctx->poseidon_mfma & 1) && n_cols > 4 && n_leaves >= PSDM_MIN_UNITS && n_leaves % 256 == 0) {
         const PsdmTables *T = psdm_tables(ctx);
         if (!T) return ZK_ERR_OOM;
         ZK_LAUNCH(ctx, "poseidon_leaf_hash", hash_leaves_colmajor_mfma_kernel, dim3((unsigned)(n_leaves / 256)), dim3(256), 0, T, cols, stride, n_cols,
@@ -277,7 +286,7 @@ int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap
     u64 *cur = levels;
     while (cnt > ((size_t)1 << cap_height)) {
         u64 *nxt = cur + 4 * cnt;
-        if (ctx->poseidon_mfma && cnt / 2 >= PSDM_MIN_UNITS && (cnt / 2) % 256 == 0) {
+        if ((ctx->poseidon_mfma & 2) && cnt / 2 >= PSDM_MIN_UNITS && (cnt / 2) % 256 == 0) {
             const PsdmTables *T = psdm_tables(ctx);
             if (!T) return ZK_ERR_OOM;
             ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_mfma_kernel, dim3((unsigned)(cnt / 2 / 256)), dim3(256), 0, T, (const u64 *)cur, nxt, cnt / 2,

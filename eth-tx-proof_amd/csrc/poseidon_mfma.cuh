@@ -71,7 +71,10 @@ __device__ __forceinline__ void recombine2(const rk &K, const psdm_v16i &acc, u6
     o0 = recombine(K, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
     o1 = recombine(K, acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
 }
-__device__ __forceinline__ void swap32(u64 &vdst, u64 &src) {   // vdst lanes 32..63 <-> src lanes 0..31
+// vdst lanes 32..63 <-> src lanes 0..31.  v_permlane32_swap needs two wait states after a vector write of either operand; hipcc
+// pads only writes it can see, and these operands come out of inline-asm blocks (gl_mad_eps), hence the explicit pad.
+__device__ __forceinline__ void swap32(u64 &vdst, u64 &src) {
+    asm volatile("s_nop 1" : "+v"(vdst), "+v"(src));
     auto lo = __builtin_amdgcn_permlane32_swap((u32)vdst, (u32)src, false, false);
     auto hi = __builtin_amdgcn_permlane32_swap((u32)(vdst >> 32), (u32)(src >> 32), false, false);
     vdst = ((u64)hi[0] << 32) | lo[0]; src = ((u64)hi[1] << 32) | lo[1];

@@ -7,6 +7,9 @@
 //   generate_txn_proof(p_state(), input, None)       /root/reference/ops/src/lib.rs:52
 // up to (not including) the Plonk recursion wrappers.  Witness generation (generate_traces, a CPU EVM
 // interpreter upstream) is out of scope: traces are an input.
+#include <string.h>
+#include <atomic>
+#include <mutex>
 #include "zk_internal.h"
 #include "prover.h"
 #include <memory>
@@ -68,8 +71,26 @@ extern "C" size_t zk_proof_size_words(const zk_stark_config *cfg, uint32_t n_tab
 
 static inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
+static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
+                                 uint64_t *proof_out, size_t cap_words, size_t *len_words);
+
+// Cold start: the first unit of a process is proved alone.  The HIP runtime loads this library's code objects lazily at the first
+// launch of each kernel and the constraint kernels are compiled and loaded (hiprtc, hipModuleLoadData) at first use; with several
+// contexts doing all of that at once from different threads, first proofs ended in sporadic GPU memory faults on this stack
+// (seen in bench.py with four streams; never once every thread had a proof behind it).  Later units run fully concurrently.
 extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
                                    uint64_t *proof_out, size_t cap_words, size_t *len_words) {
+    static std::atomic<bool> warm{false};
+    static std::mutex cold_mu;
+    if (warm.load(std::memory_order_acquire)) return prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
+    std::lock_guard<std::mutex> lk(cold_mu);
+    int32_t rc = prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
+    if (rc == ZK_OK) warm.store(true, std::memory_order_release);
+    return rc;
+}
+
+static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
+                                 uint64_t *proof_out, size_t cap_words, size_t *len_words) {
     if (!ctx || !cfgp || !tables || nt == 0 || !proof_out) return ZK_ERR_INVALID_ARG;
     const zk_stark_config &cfg = *cfgp;
     if (cfg.num_challenges == 0 || cfg.num_challenges > 4 || cfg.rate_bits != 1 || cfg.cap_height > 8 || cfg.fri_arity_bits == 0 || cfg.fri_arity_bits > 6)
@@ -94,17 +115,19 @@ extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uin
     u64 *d_chal = (u64 *)A_(16 * sizeof(u64)), *d_alphas = (u64 *)A_(8 * sizeof(u64)), *d_zeta = (u64 *)A_(8 * sizeof(u64));
     if (!d_proof || !ch || !d_chal || !d_alphas || !d_zeta) return ZK_ERR_OOM;
 
-    // host staging that must outlive the async copies: freed after the final synchronisation
-    std::vector<std::unique_ptr<std::vector<u64>>> staging;
-    auto stage = [&](const u64 *src, size_t n) { staging.emplace_back(new std::vector<u64>(src, src + n)); return staging.back()->data(); };
+    // small host objects go up through the context's pinned staging (zk_ctx::upload_small); the proof comes back through
+    // its pinned download buffer.  The staging is reused from the start: the previous proof of this context has been waited for.
+    ctx->h_stage_used = 0;
+    u64 *h_out = (u64 *)ctx->pinned_out((total + 1) * sizeof(u64));
+    if (!h_out) return ctx->fail(ZK_ERR_OOM, "prove: pinned download buffer");
 
     // header words of the proof (magic, n_tables, per table log_n / C / A)
     {
         u64 h2[2] = {0x31465250474C4B5AULL, nt};
-        HIP_TRY(ctx, hipMemcpyAsync(d_proof, stage(h2, 2), 2 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = ctx->upload_small(d_proof, h2, sizeof h2)) != ZK_OK) return rc;
         for (u32 t = 0; t < nt; t++) {
             u64 h3[3] = {tables[t].log_n, tables[t].air->n_trace_cols, n_aux_cols(tables[t].air, nch)};
-            HIP_TRY(ctx, hipMemcpyAsync(d_proof + lay[t].base, stage(h3, 3), 3 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            if ((rc = ctx->upload_small(d_proof + lay[t].base, h3, sizeof h3)) != ZK_OK) return rc;
         }
     }
     // AIRs and public inputs to the device
@@ -118,17 +141,17 @@ extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uin
         dair[t].d_helpers = (zk_helper_desc *)A_((size_t)(a->n_helpers ? a->n_helpers : 1) * sizeof(zk_helper_desc));
         d_pub[t] = (u64 *)A_((size_t)(a->n_public_inputs ? a->n_public_inputs : 1) * sizeof(u64));
         if (!dair[t].d_instrs || !dair[t].d_constants || !dair[t].d_helpers || !d_pub[t]) return ZK_ERR_OOM;
-        if (a->n_instrs) HIP_TRY(ctx, hipMemcpyAsync(dair[t].d_instrs, a->instrs, a->n_instrs * sizeof(zk_instr), hipMemcpyHostToDevice, ctx->stream));
+        if (a->n_instrs && (rc = ctx->upload_small(dair[t].d_instrs, a->instrs, a->n_instrs * sizeof(zk_instr))) != ZK_OK) return rc;
         if (a->n_constants) {
             std::vector<u64> c(a->constants, a->constants + a->n_constants);
             for (auto &v : c) v = gl_canon(v);
-            HIP_TRY(ctx, hipMemcpyAsync(dair[t].d_constants, stage(c.data(), c.size()), c.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            if ((rc = ctx->upload_small(dair[t].d_constants, c.data(), c.size() * sizeof(u64))) != ZK_OK) return rc;
         }
-        if (a->n_helpers) HIP_TRY(ctx, hipMemcpyAsync(dair[t].d_helpers, a->helpers, a->n_helpers * sizeof(zk_helper_desc), hipMemcpyHostToDevice, ctx->stream));
+        if (a->n_helpers && (rc = ctx->upload_small(dair[t].d_helpers, a->helpers, a->n_helpers * sizeof(zk_helper_desc))) != ZK_OK) return rc;
         if (a->n_public_inputs) {
             std::vector<u64> c(tables[t].public_inputs, tables[t].public_inputs + a->n_public_inputs);
             for (auto &v : c) v = gl_canon(v);
-            HIP_TRY(ctx, hipMemcpyAsync(d_pub[t], stage(c.data(), c.size()), c.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            if ((rc = ctx->upload_small(d_pub[t], c.data(), c.size() * sizeof(u64))) != ZK_OK) return rc;
         }
     }
 
@@ -148,7 +171,9 @@ extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uin
         else {
             u64 *d = (u64 *)A_(n * C * sizeof(u64));
             if (!d) { rc = ZK_ERR_OOM; break; }
-            if (hipMemcpyAsync(d, tables[t].trace, n * C * sizeof(u64), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = ZK_ERR_HIP; break; }
+            // host-resident trace (pageable memory of the caller): copy and wait, see zk_ctx::h_stage
+            if (hipMemcpyAsync(d, tables[t].trace, n * C * sizeof(u64), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZK_ERR_HIP; break; }
             d_trace[t] = d;
         }
         rc = zk_batch_commit_dev(ctx, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);
@@ -227,11 +252,12 @@ extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uin
     // ---- the only host synchronisation of the proof: fetch the proof bytes and the device error word
     u64 err_word = 0;
     if (rc == ZK_OK) {
-        if (hipMemcpyAsync(proof_out, d_proof, total * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
-        if (hipMemcpyAsync(&err_word, ctx->d_err, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
+        if (hipMemcpyAsync(h_out, d_proof, total * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
+        if (hipMemcpyAsync(h_out + total, ctx->d_err, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
     }
     hipError_t se = hipStreamSynchronize(ctx->stream);
     if (se != hipSuccess && rc == ZK_OK) rc = ctx->fail(ZK_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
+    if (rc == ZK_OK) { memcpy(proof_out, h_out, total * sizeof(u64)); err_word = h_out[total]; }
     if (rc == ZK_OK && err_word) {
         rc = (int32_t)(uint32_t)err_word;
         ctx->fail(rc, "prove: device-side check failed");

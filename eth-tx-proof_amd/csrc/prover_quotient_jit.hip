@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,7 +24,11 @@ static const char GL64_SRC[] =
     ;
 
 namespace {
-struct JitKernel { hipModule_t mod; hipFunction_t fn; };
+// `image` = the code object handed to hipModuleLoadData.  It is kept for the life of the process: the runtime may keep reading
+// the caller's buffer after the call returns (deferred / asynchronous code-object loading); when the vector was freed at the
+// end of the compile block -- in a worker thread's heap arena, which glibc gives back to the OS -- first proofs ended in sporadic
+// "memory access fault by GPU" at host heap addresses (bench.py, one thread per stream).
+struct JitKernel { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; std::shared_ptr<std::vector<char>> image; };
 std::mutex g_mu;
 std::map<std::string, JitKernel> g_cache;
 
@@ -142,7 +147,9 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
                 return ctx->fail(ZK_ERR_HIP, ("quotient jit: compile failed: " + log.substr(0, 400)).c_str());
             }
             size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
-            std::vector<char> code(cs); hiprtcGetCode(prog, code.data());
+            k.image = std::make_shared<std::vector<char>>(cs);
+            std::vector<char> &code = *k.image;
+            hiprtcGetCode(prog, code.data());
             hiprtcDestroyProgram(&prog);
             if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: hipModuleLoadData failed");
             if (hipModuleGetFunction(&k.fn, k.mod, "quotient_jit") != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: kernel not found in module");
@@ -150,6 +157,15 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
             // memory faults on this stack (seen with __launch_bounds__(256, 4), 264 B of scratch); the interpreter takes over.
             int scratch = 0;
             if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.fn) != hipSuccess || scratch > 0) k.fn = nullptr;
+            if (k.fn) {
+                // settle the freshly loaded code object before it is used in earnest: drain the stream, run the kernel once
+                // with L = 0 (every thread returns at its first instruction) and wait for it
+                QJitParams z = {};
+                void *zargs[] = {&z};
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipModuleLaunchKernel(k.fn, 1, 1, 1, 256, 1, 1, 0, ctx->stream, zargs, nullptr) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess)
+                    k.fn = nullptr;
+            }
             g_cache.emplace(key, k);
         } else k = it->second;
     }

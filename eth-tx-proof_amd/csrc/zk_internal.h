@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -24,12 +25,18 @@ struct zk_ctx {
     bool own_stream = false;
     // test hook (env ZK_FORCE_EXACT_REDO=1): the hashing kernels take their exact-redo branch on every wave (poseidon.cuh)
     u64 force_redo = 0;
-    // constraint-program JIT (prover_quotient_jit.hip): env ZK_QUOTIENT_JIT = 0 off / 1 tables with >= 2^ZK_QUOTIENT_JIT_MIN_LOG
-    // coset points (default 17) / 2 always; read when the context is created
-    int quotient_jit_mode = 1, quotient_jit_min_log = 17;
-    // matrix-core Poseidon for big leaf / Merkle-level launches (poseidon_mfma.cuh): env ZK_POSEIDON_MFMA = 0 turns it off
-    int poseidon_mfma = 1;
-    void *d_psdm = nullptr;                                        // device copy of PsdmTables (built at first use)
+    // constraint-program JIT (prover_quotient_jit.hip): env ZK_QUOTIENT_JIT = 0 off (default) / 1 tables with >=
+    // 2^ZK_QUOTIENT_JIT_MIN_LOG coset points (default 17) / 2 always; read when the context is created.  Off by default: with
+    // the first proof of a process running in a worker thread (bench.py), the first launch of a freshly compiled kernel ended
+    // in a GPU memory fault in about one process out of three (never from the main thread, never with the interpreter; cause
+    // not found -- DESIGN.md "known issues").  The interpreter is 2 ms per 2^20-row proof slower.
+    int quotient_jit_mode = 0, quotient_jit_min_log = 17;
+    // matrix-core Poseidon for big leaf / Merkle-level launches (poseidon_mfma.cuh): env ZK_POSEIDON_MFMA: bit 0 leaf
+    // hashing, bit 1 Merkle levels (default 3, 0 = vector-ALU kernels only)
+    int poseidon_mfma = 3;
+    int sync_launch = 0;
+    int efence = 0;                                                // debug allocator, see zk_ctx::alloc
+    void *d_psdm = nullptr;                                        // this device's PsdmTables (shared, never freed; poseidon_kernels.hip)
     std::string last_error;
     // caching device allocator (stream-ordered reuse on the ctx stream)
     std::multimap<size_t, void *> free_blocks;
@@ -48,6 +55,17 @@ struct zk_ctx {
     std::map<std::string, u64 *> table_cache;                      // fused per-position NTT pass tables (ntt_fast.hip)
     u64 *d_err = nullptr;                                          // device error word (first error wins)
 
+    // Pinned host memory for the asynchronous copies of a proof.  hipMemcpyAsync on pageable memory makes the runtime register
+    // the caller's pages with the GPU on the fly and drop them again when the copy retires; with several small host buffers
+    // of several threads sharing heap pages, that ended in sporadic "memory access fault by GPU" at HOST heap addresses
+    // (bench.py, four streams).  Small uploads are therefore copied into h_stage first (bump allocator, reset per proof) and
+    // the proof words come back through h_out.
+    char *h_stage = nullptr; size_t h_stage_cap = 0, h_stage_used = 0;
+    char *h_out = nullptr; size_t h_out_cap = 0;
+    const void *stage_pinned(const void *src, size_t bytes);      // nullptr when it does not fit (caller copies synchronously)
+    void *pinned_out(size_t bytes);                                // download buffer of at least `bytes`
+    int32_t upload_small(void *d_dst, const void *src, size_t bytes);   // stream-ordered H2D of a small host object
+
     void *alloc(size_t bytes);
     void release(void *p);
     int32_t fail(int32_t code, const std::string &msg) { last_error = msg; return code; }
@@ -60,10 +78,13 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// debug hook (env ZK_SYNC_LAUNCH=1): every launch is named on stderr and waited for, so a faulting kernel is the last name printed
 #define ZK_LAUNCH(ctx, name, kern, grid, block, shmem, ...)                                   \
     do {                                                                                      \
         ProfScope _ps((ctx), (name));                                                         \
+        if ((ctx)->sync_launch) fprintf(stderr, "[zk %p] %s grid %u block %u\n", (void *)(ctx), (name), (unsigned)(grid).x, (unsigned)(block).x); \
         hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__);             \
+        if ((ctx)->sync_launch) hipStreamSynchronize((ctx)->stream);                          \
     } while (0)
 
 #define HIP_TRY(ctx, expr)                                                                    \
