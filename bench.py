@@ -206,26 +206,31 @@ def main():
         else:
             per_launch = ab * proofs0 / dlaunch                    # algorithmic bytes per launch
             achieved = per_launch / (dms / dlaunch * 1e-3) / 1e9   # GB/s
-        traffic = None
-        try:   # HBM bytes from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["leaf_hash_93cols"]
+        traffic, pm = None, None
+        try:   # HBM bytes and instruction mix from the committed rocprofv3 PMC passes (profiles/r01d_pmc_leaf_hash.json)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_leaf_hash.json")))["leaf_hash_93cols"]
             if dname == "poseidon_leaf_hash" and per_launch:
                 traffic = per_launch * pm["pmc_bytes"] / pm["algorithmic_bytes"]
         except Exception:
-            traffic = None
+            traffic, pm = None, None
         # integer-ALU picture of the same kernel: permutations/s against the VALU-issue bound of the instruction stream
         perms = proofs0 * (2 * n * (-(-C // 8)) + 2 * n * (-(-A // 8) if A > 4 else 0))
         alu = None
         if dname == "poseidon_leaf_hash":
-            alu = {"permutations_per_s": perms / (dms * 1e-3), "valu_instr_per_permutation": 25100,
-                   "note": "SQ counters (profiles/r01_pmc_sq_counters_commit_bench.csv): the kernel issues VALU back to back; "
-                           "at ~3.5 SIMD-cycles per wave-instruction the chip bound is ~1.8e9 permutations/s"}
+            vw = pm["valu_instr_per_wave_permutation"] if pm else None
+            alu = {"permutations_per_s": perms / (dms * 1e-3),
+                   "valu_instr_per_wave_of_64_permutations": vw,
+                   "mfma_i8_instr_per_wave_of_64_permutations": pm["mfma_i8_instr_per_wave_permutation"] if pm else None,
+                   "valu_issue_bound_permutations_per_s": (1024 * 2.1e9 / (4.0 * vw) * 64) if vw else None,
+                   "note": "SQ counters (profiles/r01d_pmc_summary_commit_bench.json): the linear layers run on the i8 matrix cores "
+                           "(234 v_mfma_i32_32x32x32_i8 per 64 permutations), the s-boxes and limb recombination on the vector ALU; "
+                           "the bound quoted is 1024 SIMDs x ~2.1 GHz / (4 cycles x VALU instructions per 64-permutation wave)"}
         roof = {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "alu": alu,
                 "avg_launch_ms": dms / dlaunch, "avg_launch_ms_alone": solo_avg_ms, "launches": dlaunch, "algorithmic_bytes_per_launch": per_launch,
                 "share_of_kernel_time": dms / tot_ms,
-                "note": "Poseidon hashing is integer-ALU-bound (about 26k VALU instructions per permutation); the HBM "
-                        "fraction is reported as the contract asks, see DESIGN.md for the ALU roofline"}
+                "note": "Poseidon hashing is integer-ALU-bound (about 11k vector instructions + 234 matrix-core instructions per 64 "
+                        "permutations); the HBM fraction is reported as the contract asks, see DESIGN.md for the ALU roofline"}
         # NTT GB/s (second half of BASELINE.json's metric): all NTT pass kernels, algorithmic 16 B per element per transform
         ntt_ms = sum(ms for k, (_, ms) in solo.items() if k.startswith("ntt_"))      # NTT kernels of one unit run alone
         L = n << cfg.rate_bits

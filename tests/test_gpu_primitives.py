@@ -217,3 +217,52 @@ def test_forced_exact_redo_matches(zk, orc, monkeypatch):
         assert rc == 0 and (proof == ref).all()
     finally:
         c2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,ncols,rate_bits", [(14, 21, 1), (13, 93, 2), (15, 8, 1), (14, 40, 1)])
+def test_matrix_core_poseidon_equals_vector_alu_and_oracle(zk, orc, monkeypatch, log_n, ncols, rate_bits):
+    """Big commits hash their leaves and their wide Merkle levels with the matrix-core permutation (poseidon_mfma.cuh,
+    >= 16384 leaves / parents); ZK_POSEIDON_MFMA=0 keeps the one-thread-per-permutation kernels.  Both must give the oracle's
+    cap and digests, also when every wave is sent through the exact-redo branch; rows that need the rare borrow repair
+    (S-box input 2^63 in the first round) are planted in the values of a rate_bits-0 commit, where leaves are the values."""
+    rng = np.random.default_rng(log_n * 100 + ncols)
+    vals = field_rand(rng, (ncols, 1 << log_n))
+    o = orc.Batch(vals, rate_bits=rate_bits, cap_height=4)
+    for mode, redo in (("3", "0"), ("0", "0"), ("3", "1"), ("1", "0"), ("2", "0")):
+        monkeypatch.setenv("ZK_POSEIDON_MFMA", mode)
+        monkeypatch.setenv("ZK_FORCE_EXACT_REDO", redo)
+        c = zk.Context(0)
+        try:
+            b = c.batch_from_values(vals, rate_bits=rate_bits, cap_height=4)
+            assert (b.cap == o.cap).all(), (mode, redo)
+            assert (b.digests() == o.digests).all(), (mode, redo)
+            for leaf in (0, 1, 12345 % (1 << (log_n + rate_bits)), (1 << (log_n + rate_bits)) - 1):
+                assert (b.prove(leaf) == o.prove(leaf)).all()
+            b.free()
+        finally:
+            c.close()
+
+
+@pytest.mark.gpu
+def test_matrix_core_poseidon_rare_repair_rows(zk, orc, monkeypatch):
+    """leaves that really need the skipped borrow repair, hashed by the matrix-core kernel (rate_bits 0: leaves = the values)"""
+    import json, os
+    rc = [int(x, 16) for x in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon_rc.json")))["round_constants_hex"]]
+    rng = np.random.default_rng(77)
+    log_n, ncols = 14, 19
+    # a rate_bits-0 commit stores LDE = NTT(iNTT(values)) = values, in bit-reversed row order
+    vals = field_rand(rng, (ncols, 1 << log_n))
+    for r in range(5, 1 << log_n, 97):
+        j = r % 8
+        vals[j, r] = ((1 << 63) - rc[j]) % P
+    o = orc.Batch(vals, rate_bits=0, cap_height=4)
+    for mode in ("3", "0"):
+        monkeypatch.setenv("ZK_POSEIDON_MFMA", mode)
+        c = zk.Context(0)
+        try:
+            b = c.batch_from_values(vals, rate_bits=0, cap_height=4)
+            assert (b.cap == o.cap).all() and (b.digests() == o.digests).all(), mode
+            b.free()
+        finally:
+            c.close()
