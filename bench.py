@@ -129,6 +129,9 @@ def main():
         outs.append(np.empty(zl.proof_size_words(cfg, [(prog, args.log_n, t.data_ptr(), pub)]), dtype=np.uint64))
     for c in ctxs:
         c.synchronize()
+    # prover state (the reference builds it once at start-up, common/src/prover_state/mod.rs:59-95): a no-op unless the
+    # constraint JIT is switched on (ZK_QUOTIENT_JIT >= 0, off by default: zk_internal.h)
+    zl.prover_state_prepare(ctxs[0], cfg, [(prog, args.log_n, traces[0].data_ptr(), pubs[0])])
 
     errors = []
 

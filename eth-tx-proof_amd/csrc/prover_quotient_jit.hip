@@ -114,22 +114,61 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits) {
 }
 }  // namespace
 
+// mode -1: never; 0 (default): only kernels compiled ahead of time by zk_prover_state_prepare; 1: compile at first use for tables
+// with >= 2^min_log coset points; 2: compile at first use, always
 bool zk_quotient_jit_enabled(const zk_ctx *ctx, size_t L) {
-    return ctx->quotient_jit_mode == 2 || (ctx->quotient_jit_mode == 1 && L >= ((size_t)1 << ctx->quotient_jit_min_log));
+    if (ctx->quotient_jit_mode < 0) return false;
+    return ctx->quotient_jit_mode == 2 || L >= ((size_t)1 << ctx->quotient_jit_min_log);
 }
 
+static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k);
+
 int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, QJitParams &p) {
+    JitKernel k;
+    int32_t rc = jit_get(ctx, air, C, A, nch, rate_bits, ctx->quotient_jit_mode >= 1, k);
+    if (rc != ZK_OK) return rc;
+    if (!k.fn) return ZK_JIT_UNAVAILABLE;
+    void *args[] = {&p};
+    const unsigned blocks = (unsigned)((p.L + 255) / 256);
+    hipError_t e;
+    { ProfScope ps(ctx, "quotient_eval"); e = hipModuleLaunchKernel(k.fn, blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr); }
+    if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: launch failed");
+    return ZK_OK;
+}
+
+// The counterpart of the reference building its prover state once at start-up (/root/reference/common/src/prover_state/mod.rs:59-95,
+// reached from ops::p_state, /root/reference/ops/src/lib.rs:16-18): compile the constraint kernels of the given tables now, in
+// the calling thread, so that proofs never compile.  Call it from the thread that created the context, before units are handed
+// to worker threads.
+extern "C" int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables) {
+    if (!ctx || !cfg || (!tables && n_tables)) return ZK_ERR_INVALID_ARG;
+    if (ctx->quotient_jit_mode < 0) return ZK_OK;
+    hipSetDevice(ctx->device);
+    for (uint32_t t = 0; t < n_tables; t++) {
+        const zk_air *air = tables[t].air;
+        if (!air) return ZK_ERR_INVALID_ARG;
+        const size_t L = (size_t)1 << (tables[t].log_n + cfg->rate_bits);
+        if (!zk_quotient_jit_enabled(ctx, L)) continue;
+        const u32 nch = cfg->num_challenges, A = air->n_helpers ? nch * (air->n_helpers + 1) : 0;
+        JitKernel k;
+        int32_t rc = jit_get(ctx, air, air->n_trace_cols, A, nch, cfg->rate_bits, true, k);
+        if (rc != ZK_OK) return rc;
+    }
+    return ZK_OK;
+}
+
+static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k) {
     // cache key: everything the generated source depends on, verbatim
     std::string key;
     u32 hdr[8] = {(u32)ctx->device, C, A, nch, rate_bits, air->n_regs, air->n_instrs, air->n_constants};
     key.append((const char *)hdr, sizeof hdr);
     key.append((const char *)air->instrs, (size_t)air->n_instrs * sizeof(zk_instr));
     key.append((const char *)air->constants, (size_t)air->n_constants * sizeof(u64));
-    JitKernel k;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_cache.find(key);
         if (it == g_cache.end()) {
+            if (!may_compile) { k = JitKernel(); return ZK_OK; }
             std::string src = generate(air, C, A, nch, rate_bits);
             if (const char *dump = getenv("ZK_QUOTIENT_JIT_DUMP")) {       // debugging aid: the generated source, for offline inspection
                 if (FILE *f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
@@ -169,11 +208,5 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
             g_cache.emplace(key, k);
         } else k = it->second;
     }
-    if (!k.fn) return ZK_JIT_UNAVAILABLE;
-    void *args[] = {&p};
-    const unsigned blocks = (unsigned)((p.L + 255) / 256);
-    hipError_t e;
-    { ProfScope ps(ctx, "quotient_eval"); e = hipModuleLaunchKernel(k.fn, blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr); }
-    if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: launch failed");
     return ZK_OK;
 }

@@ -25,12 +25,13 @@ struct zk_ctx {
     bool own_stream = false;
     // test hook (env ZK_FORCE_EXACT_REDO=1): the hashing kernels take their exact-redo branch on every wave (poseidon.cuh)
     u64 force_redo = 0;
-    // constraint-program JIT (prover_quotient_jit.hip): env ZK_QUOTIENT_JIT = 0 off (default) / 1 tables with >=
-    // 2^ZK_QUOTIENT_JIT_MIN_LOG coset points (default 17) / 2 always; read when the context is created.  Off by default: with
-    // the first proof of a process running in a worker thread (bench.py), the first launch of a freshly compiled kernel ended
-    // in a GPU memory fault in about one process out of three (never from the main thread, never with the interpreter; cause
-    // not found -- DESIGN.md "known issues").  The interpreter is 2 ms per 2^20-row proof slower.
-    int quotient_jit_mode = 0, quotient_jit_min_log = 17;
+    // constraint-program JIT (prover_quotient_jit.hip): env ZK_QUOTIENT_JIT = -1 never (default) / 0 only kernels compiled ahead
+    // of time by zk_prover_state_prepare / 1 compile at first use for tables with >= 2^ZK_QUOTIENT_JIT_MIN_LOG coset points
+    // (default 17) / 2 always; read when the context is created.  Off by default: in bench.py (first proof of a process in a
+    // worker thread) the compiled kernel ended in a GPU memory fault in about one process out of three -- also when compiled
+    // ahead of time from the main thread, also with the previous round's field arithmetic; never with the interpreter (20 of 20
+    // processes), never in the test-suite or single-threaded drivers.  Cause not found: DESIGN.md "known issues".
+    int quotient_jit_mode = -1, quotient_jit_min_log = 17;
     // matrix-core Poseidon for big leaf / Merkle-level launches (poseidon_mfma.cuh): env ZK_POSEIDON_MFMA: bit 0 leaf
     // hashing, bit 1 Merkle levels (default 3, 0 = vector-ALU kernels only)
     int poseidon_mfma = 3;

@@ -334,6 +334,12 @@ def prove_tables(ctx, cfg, items, out=None):
     return out[:ln.value]
 
 
+def prover_state_prepare(ctx, cfg, items):
+    """zk_prover_state_prepare: compile the constraint kernels of the tables ahead of time (call from the main thread)."""
+    arr, keep = _tables(items)
+    ctx._chk(lib().zk_prover_state_prepare(ctx.h, C.byref(cfg), C.c_uint32(len(items)), arr), "zk_prover_state_prepare")
+
+
 def synth_trace_dev(ctx, n_cols, log_n, seed, dptr=None):
     """zk_synth_trace_dev: returns (device pointer, public inputs)."""
     if dptr is None:

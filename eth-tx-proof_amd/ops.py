@@ -62,6 +62,12 @@ class ProverState:
             self._tls.ctx = c
         return c
 
+    def prepare(self, tables):
+        """Build the compiled part of the prover state for these table shapes (zk_prover_state_prepare): the reference builds its
+        circuits once at start-up (common/src/prover_state/mod.rs:59-95).  Call from the thread that initialised the state."""
+        items = [(t.air, t.log_n, t.trace, t.public_inputs) for t in tables]
+        zl.prover_state_prepare(self.ctx(), self.config, items)
+
 
 P_STATE: Optional[ProverState] = None
 _lock = threading.Lock()

@@ -214,6 +214,11 @@ typedef struct {
 size_t zk_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables);
 int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables,
                         uint64_t *proof_out, size_t proof_cap_words, size_t *proof_len_words);
+/* Prover state: what the reference builds once at start-up (common/src/prover_state/mod.rs:59-95, used through
+ * ops::p_state, ops/src/lib.rs:16-18).  Here: the constraint programs of the given tables compiled to gfx950 code (hiprtc) and
+ * cached for the process; without this call proofs evaluate constraints with the bytecode interpreter.  Call from the thread
+ * that created the context, before handing units to worker threads.  `trace` of the tables is not read. */
+int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables);
 /* ------------------------------------------------------------------ the pieces of a unit proof, one upstream item each
  * starky::lookup::lookup_helper_columns + cross_table_lookup::partial_sums: auxiliary columns of one table for the
  * challenges [beta_0, gamma_0, beta_1, gamma_1, ..] (host in, host out; aux_out = n_aux_cols x 2^log_n column-major,

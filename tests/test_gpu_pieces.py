@@ -204,11 +204,16 @@ def test_quotient_jit_equals_interpreter_and_oracle(zk, orc, monkeypatch, n_cols
         assert rc == 0
         oab = orc.Batch(aux)
     ref = orc.quotient(cfg, prog, ob, oab, pub, ch, al)
-    for mode in ("2", "0", "2+forced redo"):       # the last: every slice flagged -> all redone by the interpreter fix-up
-        monkeypatch.setenv("ZK_QUOTIENT_JIT", mode[0])
+    # "2+forced redo": every slice flagged -> all redone by the interpreter fix-up; "0+prepared": kernels compiled ahead of
+    # time by zk_prover_state_prepare (min size lowered so that these small tables qualify); "-": never (the default)
+    for mode in ("2", "0", "2+forced redo", "0+prepared", "-"):
+        monkeypatch.setenv("ZK_QUOTIENT_JIT", "-1" if mode == "-" else mode[0])
+        monkeypatch.setenv("ZK_QUOTIENT_JIT_MIN_LOG", "1")
         monkeypatch.setenv("ZK_FORCE_EXACT_REDO", "1" if "forced" in mode else "0")
         c2 = zk.Context(0)
         try:
+            if "prepared" in mode:
+                zk.prover_state_prepare(c2, cfg, [(prog, log_n, tr, pub)])
             tb = c2.batch_from_values(tr)
             ab = c2.batch_from_values(aux) if n_helpers else None
             got = zk.quotient(c2, cfg, prog, tb, ab, pub, ch, al)
