@@ -123,7 +123,13 @@ def main():
     ctxs, traces, pubs, outs = [], [], [], []
     for s in range(args.inflight):
         c = zl.Context(local)
-        t = torch.empty((C, n), dtype=torch.int64, device=dev)
+        if os.environ.get("ZK_BENCH_CTX_TRACES"):        # debugging aid: traces from the context's allocator (fence-able)
+            class _T:                                     # same interface as the torch tensor below
+                def __init__(self, p): self.p = p
+                def data_ptr(self): return self.p
+            t = _T(c.dev_alloc(8 * C * n))
+        else:
+            t = torch.empty((C, n), dtype=torch.int64, device=dev)
         _, pub = zl.synth_trace_dev(c, C, args.log_n, 0x5EED0000 + 1000 * (rank * args.inflight + s), dptr=t.data_ptr())
         ctxs.append(c); traces.append(t); pubs.append(pub)
         outs.append(np.empty(zl.proof_size_words(cfg, [(prog, args.log_n, t.data_ptr(), pub)]), dtype=np.uint64))
