@@ -134,7 +134,7 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return ZK_ERR_HIP;
     zk_ctx *c = new zk_ctx();
     c->device = device;
-    { const char *e = getenv("ZK_FORCE_EXACT_REDO"); c->force_redo = (e && atoi(e)) ? 1 : 0; }
+    { const char *e = getenv("ZK_FORCE_EXACT_REDO"); c->force_redo = e ? (u64)atoi(e) : 0; }   // 1: every wave / slice; 2: as 1, but the compiled quotient kernel flags one slice in seven
     { const char *e = getenv("ZK_QUOTIENT_JIT"); if (e) c->quotient_jit_mode = atoi(e); }
     { const char *e = getenv("ZK_POSEIDON_MFMA"); if (e) c->poseidon_mfma = atoi(e); }
     { const char *e = getenv("ZK_SYNC_LAUNCH"); if (e) c->sync_launch = atoi(e); }

@@ -108,7 +108,8 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits) {
     s += g.body;
     appendf(s, "    const u64 zi = p.zh_inv[i & %uu];\n", (1u << rate_bits) - 1);
     for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = g.mul(acc%u, zi);\n", j, j);
-    s += "    if ((g.fl != 0) | p.force) {\n        if ((threadIdx.x & 63) == 0) { u32 k = atomicAdd(p.redo, 1u); if (k < p.redo_cap) p.redo[1 + k] = blockIdx.x; }\n    }\n";
+    // p.force: test hook -- 1 flags every slice (the fix-up kernel then redoes all of them), 2 flags one slice in seven (the list path)
+    s += "    if ((g.fl != 0) | (p.force == 1u) | ((p.force == 2u) & ((blockIdx.x % 7u) == 3u))) {\n        if ((threadIdx.x & 63) == 0) { u32 k = atomicAdd(p.redo, 1u); if (k < p.redo_cap) p.redo[1 + k] = blockIdx.x; }\n    }\n";
     s += "}\n";
     return s;
 }
