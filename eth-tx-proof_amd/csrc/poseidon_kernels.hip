@@ -74,7 +74,7 @@ template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_pair(const Psdm
     }
     return pm.pc.fl;
 }
-__global__ __launch_bounds__(256, 2) void hash_leaves_colmajor_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ cols, size_t stride,
+__global__ __launch_bounds__(256, 3) void hash_leaves_colmajor_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ cols, size_t stride,
                                                                           u32 n_cols, size_t n_leaves, u64 *__restrict__ out, u64 force_redo) {
     const u32 lane = threadIdx.x & 63;
     const size_t leaf0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(size_t)63;     // n_leaves is a multiple of 256

@@ -195,6 +195,9 @@ template <bool EXACT> struct perm {
 
     // any 64-bit representatives in, canonical out
     __device__ __forceinline__ void run(u64 (&s)[2][6]) {
+        // the table pointers are made opaque once per permutation: otherwise hipcc hoists the (loop-invariant) operand and
+        // accumulator-start loads of every layer out of the caller's loop and keeps ~100 registers alive for them
+        asm volatile("" : "+s"(T), "+v"(Alds));
         {
             const u64 *rc0 = T->RC_first + 6 * (lane >> 5);
 #pragma unroll
