@@ -136,6 +136,7 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
     c->device = device;
     { const char *e = getenv("ZK_FORCE_EXACT_REDO"); c->force_redo = e ? (u64)atoi(e) : 0; }   // 1: every wave / slice; 2: as 1, but the compiled quotient kernel flags one slice in seven
     { const char *e = getenv("ZK_QUOTIENT_JIT"); if (e) c->quotient_jit_mode = atoi(e); }
+    { const char *e = getenv("ZK_QUOTIENT_AOT"); if (e) c->quotient_aot = atoi(e); }
     { const char *e = getenv("ZK_POSEIDON_MFMA"); if (e) c->poseidon_mfma = atoi(e); }
     { const char *e = getenv("ZK_SYNC_LAUNCH"); if (e) c->sync_launch = atoi(e); }
     { const char *e = getenv("ZK_ALLOC_EFENCE"); if (e) c->efence = atoi(e); }

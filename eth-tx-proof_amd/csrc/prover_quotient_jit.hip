@@ -11,6 +11,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -75,7 +76,7 @@ struct Gen {
     }
 };
 
-std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits) {
+std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname = "quotient_jit", bool standalone = true) {
     Gen g; g.air = air; g.C = C; g.A = A;
     g.have_l.assign(C + A, 0); g.have_n.assign(C + A, 0); g.have_pub.assign(air->n_public_inputs + 1, 0);
     for (u32 pc = 0; pc < air->n_instrs; pc++) {
@@ -94,9 +95,11 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits) {
         }
     }
     std::string s;
-    s += "#include \"gl64.cuh\"\n";
-    s += "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u32 *redo; u32 redo_cap; u32 pad; };\n";
-    s += "extern \"C\" __global__ __launch_bounds__(256) void quotient_jit(QJitParams p) {\n";
+    if (standalone) {
+        s += "#include \"gl64.cuh\"\n";
+        s += "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u32 *redo; u32 redo_cap; u32 pad; };\n";
+    }
+    appendf(s, "extern \"C\" __global__ __launch_bounds__(256) void %s(QJitParams p) {\n", kname);
     s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
     s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
     appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
@@ -115,16 +118,65 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits) {
 }
 }  // namespace
 
+// everything the generated source depends on, verbatim (the cache key of compiled kernels; its FNV-1a hash names ahead-of-time ones)
+static std::string air_key(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits) {
+    std::string key;
+    u32 hdr[7] = {C, A, nch, rate_bits, air->n_regs, air->n_instrs, air->n_constants};
+    key.append((const char *)hdr, sizeof hdr);
+    key.append((const char *)air->instrs, (size_t)air->n_instrs * sizeof(zk_instr));
+    key.append((const char *)air->constants, (size_t)air->n_constants * sizeof(u64));
+    return key;
+}
+static u64 fnv1a(const std::string &s) {
+    u64 h = 0xcbf29ce484222325ULL;
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ULL; }
+    return h;
+}
+// prover_quotient_aot.hip (generated by tools/gen_aot_quotient.py): kernels compiled with the library for the AIRs known at build time
+const void *zk_quotient_aot_lookup(u64 key_hash);
+
+// The source of the constraint kernel of one AIR, for the build-time generator (host only, no GPU needed).
+extern "C" int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_challenges, uint32_t rate_bits, char *buf, size_t cap,
+                                             size_t *len, uint64_t *key_hash) {
+    if (!air || !len || !key_hash) return ZK_ERR_INVALID_ARG;
+    const u32 A = air->n_helpers ? num_challenges * (air->n_helpers + 1) : 0;
+    const u64 h = fnv1a(air_key(air, air->n_trace_cols, A, num_challenges, rate_bits));
+    char name[64]; snprintf(name, sizeof name, "quotient_aot_%016llx", (unsigned long long)h);
+    std::string src = generate(air, air->n_trace_cols, A, num_challenges, rate_bits, name, false);
+    *len = src.size(); *key_hash = h;
+    if (buf) { if (cap < src.size() + 1) return ZK_ERR_BUFFER_TOO_SMALL; memcpy(buf, src.c_str(), src.size() + 1); }
+    return ZK_OK;
+}
+
 // mode -1: never; 0 (default): only kernels compiled ahead of time by zk_prover_state_prepare; 1: compile at first use for tables
 // with >= 2^min_log coset points; 2: compile at first use, always
 bool zk_quotient_jit_enabled(const zk_ctx *ctx, size_t L) {
-    if (ctx->quotient_jit_mode < 0) return false;
-    return ctx->quotient_jit_mode == 2 || L >= ((size_t)1 << ctx->quotient_jit_min_log);
+    if (ctx->quotient_jit_mode == 2) return true;
+    if (L < ((size_t)1 << ctx->quotient_jit_min_log)) return false;
+    return ctx->quotient_jit_mode >= 0 || ctx->quotient_aot;       // ahead-of-time kernels need no run-time compiler
 }
 
 static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k);
 
 int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, QJitParams &p) {
+    if (ctx->quotient_aot) {
+        // a kernel for this very program was compiled with the library: an ordinary launch, no hiprtc, no module loading
+        if (const void *fn = zk_quotient_aot_lookup(fnv1a(air_key(air, C, A, nch, rate_bits)))) {
+            void *args[] = {&p};
+            hipError_t e;
+            // ZK_DEBUG_QSYNC (default 2): bit 0 = wait for the stream before the launch, bit 1 = after it.  Without the wait AFTER
+            // the compiled kernel, a 2^20-row proof faults deterministically ("memory access fault by GPU", tools/prove_twice.py 20)
+            // although neither this kernel nor the kernels enqueued behind it form an address from data; with it, never.  The wait
+            // before it changes nothing.  Not understood; the wait costs one host round trip per table.
+            static const int qsync = getenv("ZK_DEBUG_QSYNC") ? atoi(getenv("ZK_DEBUG_QSYNC")) : 2;
+            if (qsync & 1) hipStreamSynchronize(ctx->stream);
+            { ProfScope ps(ctx, "quotient_eval"); e = hipLaunchKernel(fn, dim3((unsigned)((p.L + 255) / 256)), dim3(256), args, 0, ctx->stream); }
+            if (qsync & 2) hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient aot: launch failed");
+            return ZK_OK;
+        }
+    }
+    if (ctx->quotient_jit_mode < 0) return ZK_JIT_UNAVAILABLE;
     JitKernel k;
     int32_t rc = jit_get(ctx, air, C, A, nch, rate_bits, ctx->quotient_jit_mode >= 1, k);
     if (rc != ZK_OK) return rc;
@@ -159,12 +211,8 @@ extern "C" int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *c
 }
 
 static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k) {
-    // cache key: everything the generated source depends on, verbatim
-    std::string key;
-    u32 hdr[8] = {(u32)ctx->device, C, A, nch, rate_bits, air->n_regs, air->n_instrs, air->n_constants};
-    key.append((const char *)hdr, sizeof hdr);
-    key.append((const char *)air->instrs, (size_t)air->n_instrs * sizeof(zk_instr));
-    key.append((const char *)air->constants, (size_t)air->n_constants * sizeof(u64));
+    std::string key = air_key(air, C, A, nch, rate_bits);
+    { u32 dev = (u32)ctx->device; key.append((const char *)&dev, sizeof dev); }
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_cache.find(key);

@@ -219,6 +219,12 @@ int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tabl
  * cached for the process; without this call proofs evaluate constraints with the bytecode interpreter.  Call from the thread
  * that created the context, before handing units to worker threads.  `trace` of the tables is not read. */
 int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables);
+/* Build-time half of the same idea (upstream's constraints are Rust code monomorphised when the prover is built): the HIP source of
+ * the constraint kernel of one AIR and the hash that names it.  Host only (no context, no GPU); tools/gen_aot_quotient.py writes
+ * the kernels of the AIRs known at build time into csrc/prover_quotient_aot.hip, which is compiled with the library.
+ * buf may be NULL to query the length. */
+int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_challenges, uint32_t rate_bits, char *buf, size_t cap,
+                                  size_t *len, uint64_t *key_hash);
 /* ------------------------------------------------------------------ the pieces of a unit proof, one upstream item each
  * starky::lookup::lookup_helper_columns + cross_table_lookup::partial_sums: auxiliary columns of one table for the
  * challenges [beta_0, gamma_0, beta_1, gamma_1, ..] (host in, host out; aux_out = n_aux_cols x 2^log_n column-major,
