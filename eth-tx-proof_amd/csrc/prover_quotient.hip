@@ -37,43 +37,126 @@ __device__ __forceinline__ u64 q_fetch(const QParams &p, u32 o, const u64 *sh, u
     }
 }
 
-// one workgroup-sized slice of the coset (256 points from `block`*256) through the bytecode interpreter
-__device__ __forceinline__ void quotient_block(const QParams &p, u32 block, u64 *sh) {
+// one workgroup-sized slice of the coset (256*NP points from `block`*256*NP) through the bytecode interpreter.  NP = 2: every thread
+// carries two points (s and s + 256), so instruction fetch, decode and the operand-kind dispatch -- two thirds of the interpreter's
+// instruction stream -- are paid once for two evaluations; both points' accesses stay coalesced.
+// EXACT = false: products through glx<false> (gl64.cuh: the two 1-in-2^32 repairs skipped behind a wave-uniform sticky word); the
+// caller re-runs the slice with EXACT = true when the word comes back non-zero, so the stored values are the same bit for bit.
+template <int NP, bool EXACT> __device__ __forceinline__ u64 quotient_block(const QParams &p, u32 block, u64 *sh) {
+    glx<EXACT> g; g.fl = 0;
+    const u32 n_instrs = (u32)__builtin_amdgcn_readfirstlane((int)p.n_instrs), nch = (u32)__builtin_amdgcn_readfirstlane((int)p.nch);   // wave-uniform, and known to be
     const u32 t = threadIdx.x;
-    const size_t s = (size_t)block * 256 + t;
-    if (s >= p.L) return;
-    const u32 i = bitrev_u32((u32)s, p.lgL);
-    const size_t sn = bitrev_u32((i + (1u << p.rate_bits)) & (u32)(p.L - 1), p.lgL);
-    const u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);
-    const u64 z_last = gl_sub(x, p.last_inv);
-    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];
-    u64 acc[4] = {0, 0, 0, 0};
-    u64 al[4];
+    size_t s[NP], sn[NP]; u32 i[NP]; u64 z_last[NP], l_first[NP], l_last[NP];
+    u64 acc[NP][4], al[4];
+    bool live[NP];
 #pragma unroll
-    for (int j = 0; j < 4; j++) al[j] = j < (int)p.nch ? p.alphas[j] : 0;
-    for (u32 pc = 0; pc < p.n_instrs; pc++) {
-        const zk_instr in = p.instrs[pc];
-        u64 a = q_fetch(p, in.a, sh, t, s, sn);
+    for (int k = 0; k < NP; k++) {
+        s[k] = (size_t)block * (256 * NP) + 256 * k + t;
+        live[k] = s[k] < p.L;
+        const size_t sc = live[k] ? s[k] : 0;                    // dead points (ragged tail) evaluate point 0 and store nothing
+        i[k] = bitrev_u32((u32)sc, p.lgL);
+        sn[k] = bitrev_u32((i[k] + (1u << p.rate_bits)) & (u32)(p.L - 1), p.lgL);
+        s[k] = sc;
+        const u64 x = g.mul(p.xA[i[k] & 2047], p.xB[i[k] >> 11]);
+        z_last[k] = gl_sub(x, p.last_inv);
+        l_first[k] = p.lag[sc]; l_last[k] = p.lag[p.L + sc];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[k][j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) al[j] = j < (int)nch ? p.alphas[j] : 0;
+    for (u32 pc = 0; pc < n_instrs; pc++) {
+        // the instruction word is the same for every lane; saying so keeps the whole loop body in wave-uniform control flow,
+        // which the scalar sticky word of glx<false> needs
+        zk_instr in = p.instrs[pc];
+        in.op = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.op); in.dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.dst);
+        in.a = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.a); in.b = (uint32_t)__builtin_amdgcn_readfirstlane((int)in.b);
+        u64 a[NP];
+        {
+            const u32 kind = in.a >> 24, idx = in.a & 0xFFFFFF;
+            switch (kind) {
+            case ZK_OPND_REG:
+#pragma unroll
+                for (int k = 0; k < NP; k++) a[k] = sh[(idx * NP + k) * 256 + t];
+                break;
+            case ZK_OPND_LOCAL: {
+                const u64 *col = idx < p.C ? p.trace_lde + (size_t)idx * p.L : p.aux_lde + (size_t)(idx - p.C) * p.L;
+#pragma unroll
+                for (int k = 0; k < NP; k++) a[k] = col[s[k]];
+                break; }
+            case ZK_OPND_NEXT: {
+                const u64 *col = idx < p.C ? p.trace_lde + (size_t)idx * p.L : p.aux_lde + (size_t)(idx - p.C) * p.L;
+#pragma unroll
+                for (int k = 0; k < NP; k++) a[k] = col[sn[k]];
+                break; }
+            default: {
+                const u64 v = kind == ZK_OPND_CONST ? p.constants[idx] : kind == ZK_OPND_PUBLIC ? p.pub[idx] : p.chal[idx];
+#pragma unroll
+                for (int k = 0; k < NP; k++) a[k] = v;
+                break; }
+            }
+        }
         if (in.op <= ZK_OP_MUL) {
-            u64 b = q_fetch(p, in.b, sh, t, s, sn);
-            u64 r = in.op == ZK_OP_ADD ? gl_add(a, b) : in.op == ZK_OP_SUB ? gl_sub(a, b) : gl_mul(a, b);
-            sh[(in.dst & 0xFFFFFF) * 256 + t] = r;
-        } else {
-            u64 c = a;
-            if (in.op == ZK_OP_EMIT_TRANSITION) c = gl_mul(a, z_last);
-            else if (in.op == ZK_OP_EMIT_FIRST) c = gl_mul(a, l_first);
-            else if (in.op == ZK_OP_EMIT_LAST) c = gl_mul(a, l_last);
+            u64 b[NP];
+            const u32 kind = in.b >> 24, idx = in.b & 0xFFFFFF;
+            switch (kind) {
+            case ZK_OPND_REG:
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (j < (int)p.nch) acc[j] = gl_mul_add(acc[j], al[j], c);
+                for (int k = 0; k < NP; k++) b[k] = sh[(idx * NP + k) * 256 + t];
+                break;
+            case ZK_OPND_LOCAL: {
+                const u64 *col = idx < p.C ? p.trace_lde + (size_t)idx * p.L : p.aux_lde + (size_t)(idx - p.C) * p.L;
+#pragma unroll
+                for (int k = 0; k < NP; k++) b[k] = col[s[k]];
+                break; }
+            case ZK_OPND_NEXT: {
+                const u64 *col = idx < p.C ? p.trace_lde + (size_t)idx * p.L : p.aux_lde + (size_t)(idx - p.C) * p.L;
+#pragma unroll
+                for (int k = 0; k < NP; k++) b[k] = col[sn[k]];
+                break; }
+            default: {
+                const u64 v = kind == ZK_OPND_CONST ? p.constants[idx] : kind == ZK_OPND_PUBLIC ? p.pub[idx] : p.chal[idx];
+#pragma unroll
+                for (int k = 0; k < NP; k++) b[k] = v;
+                break; }
+            }
+            const u32 dst = in.dst & 0xFFFFFF;
+            if (in.op == ZK_OP_ADD) {
+#pragma unroll
+                for (int k = 0; k < NP; k++) sh[(dst * NP + k) * 256 + t] = gl_add(a[k], b[k]);
+            } else if (in.op == ZK_OP_SUB) {
+#pragma unroll
+                for (int k = 0; k < NP; k++) sh[(dst * NP + k) * 256 + t] = gl_sub(a[k], b[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NP; k++) sh[(dst * NP + k) * 256 + t] = g.mul(a[k], b[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                // the filter is a select, the product unconditional (a plain EMIT multiplies by 1): no branch around a product
+                const u64 m = in.op == ZK_OP_EMIT_TRANSITION ? z_last[k] : in.op == ZK_OP_EMIT_FIRST ? l_first[k] : in.op == ZK_OP_EMIT_LAST ? l_last[k] : 1;
+                const u64 c = g.mul(a[k], m);
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j < (int)nch) acc[k][j] = g.mul_add(acc[k][j], al[j], c);
+            }
         }
     }
-    const u64 zi = p.zh_inv[i & ((1u << p.rate_bits) - 1)];
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (j < (int)p.nch) p.out[(size_t)j * p.L + s] = gl_mul(acc[j], zi);
+    for (int k = 0; k < NP; k++) {
+        const u64 zi = p.zh_inv[i[k] & ((1u << p.rate_bits) - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j < (int)nch) {
+            const u64 q = g.mul(acc[k][j], zi);                      // products stay outside lane-dependent control flow
+            if (live[k]) p.out[(size_t)j * p.L + s[k]] = q;
+        }
+    }
+    return g.fl;
 }
-__global__ __launch_bounds__(256) void quotient_kernel(QParams p) {
+__global__ __launch_bounds__(256) void quotient_kernel(QParams p, u64 force_redo) {
     extern __shared__ u64 sh[];
-    quotient_block(p, blockIdx.x, sh);
+    // temporaries are [reg][point][thread]: a wave only ever touches its own lanes' slots, so a flagged wave can redo its part alone
+    if (quotient_block<2, false>(p, blockIdx.x, sh) | force_redo) quotient_block<2, true>(p, blockIdx.x, sh);
 }
 // Exact redo of the slices in which the compiled kernel (prover_quotient_jit.hip) skipped a rare repair: redo[0] = number of
 // pushed slice ids, redo[1..cap] = the ids.  More pushes than `cap` (never seen; forced by the test hook): every slice.
@@ -82,9 +165,9 @@ __global__ __launch_bounds__(256) void quotient_fixup_kernel(QParams p, const u3
     const u32 count = redo[0];
     if (count == 0) return;
     if (count <= cap) {
-        for (u32 k = blockIdx.x; k < count; k += gridDim.x) { quotient_block(p, redo[1 + k], sh); __syncthreads(); }
+        for (u32 k = blockIdx.x; k < count; k += gridDim.x) { quotient_block<1, true>(p, redo[1 + k], sh); __syncthreads(); }
     } else {
-        for (u32 b = blockIdx.x; b < total_blocks; b += gridDim.x) { quotient_block(p, b, sh); __syncthreads(); }
+        for (u32 b = blockIdx.x; b < total_blocks; b += gridDim.x) { quotient_block<1, true>(p, b, sh); __syncthreads(); }
     }
 }
 
@@ -125,7 +208,7 @@ int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &c
     if (nch > 4 || rate_bits > 3) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: num_challenges <= 4, rate_bits <= 3");
     if (air.host->constraint_degree != 3 || rate_bits != 1)   // quotient_degree_bits == rate_bits == 1
         return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: only constraint degree 3 with rate_bits 1 is supported");
-    if (air.host->n_regs * 256 * sizeof(u64) > 64 * 1024) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: too many registers");
+    if (air.host->n_regs * 512 * sizeof(u64) > 64 * 1024) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: too many registers");
     QParams p = {};
     p.instrs = air.d_instrs; p.n_instrs = air.host->n_instrs; p.n_regs = air.host->n_regs;
     p.constants = air.d_constants; p.pub = d_public; p.chal = d_chal; p.alphas = d_alphas;
@@ -163,7 +246,7 @@ int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &c
         ctx->release(redo);
         if (rc != ZK_OK && rc != ZK_JIT_UNAVAILABLE) return rc;
     }
-    if (!done) ZK_LAUNCH(ctx, "quotient_eval", quotient_kernel, dim3(blocks), dim3(256), shmem, p);
+    if (!done) ZK_LAUNCH(ctx, "quotient_eval", quotient_kernel, dim3((unsigned)((L + 511) / 512)), dim3(256), 2 * shmem, p, ctx->force_redo);
     // coset_ifft(g): leaf-order values -> natural-order coefficients, scaled by L^-1 g^-j.  In place.
     TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);
     return zk_ntt_dit(ctx, d_qcoeffs, L, d_qcoeffs, L, lgL, nch, 1, nullptr, &post, 0, nullptr, 0);
