@@ -220,7 +220,7 @@ def test_forced_exact_redo_matches(zk, orc, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_n,ncols,rate_bits", [(14, 21, 1), (13, 93, 2), (15, 8, 1), (14, 40, 1)])
+@pytest.mark.parametrize("log_n,ncols,rate_bits", [(14, 21, 1), (13, 93, 2), (15, 8, 1), (14, 40, 1), (14, 5, 1), (13, 135, 1), (15, 9, 0), (14, 16, 0)])
 def test_matrix_core_poseidon_equals_vector_alu_and_oracle(zk, orc, monkeypatch, log_n, ncols, rate_bits):
     """Big commits hash their leaves and their wide Merkle levels with the matrix-core permutation (poseidon_mfma.cuh,
     >= 16384 leaves / parents); ZK_POSEIDON_MFMA=0 keeps the one-thread-per-permutation kernels.  Both must give the oracle's
