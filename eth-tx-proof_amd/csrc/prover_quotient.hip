@@ -158,19 +158,6 @@ __global__ __launch_bounds__(256) void quotient_kernel(QParams p, u64 force_redo
     // temporaries are [reg][point][thread]: a wave only ever touches its own lanes' slots, so a flagged wave can redo its part alone
     if (quotient_block<2, false>(p, blockIdx.x, sh) | force_redo) quotient_block<2, true>(p, blockIdx.x, sh);
 }
-// Exact redo of the slices in which the compiled kernel (prover_quotient_jit.hip) skipped a rare repair: redo[0] = number of
-// pushed slice ids, redo[1..cap] = the ids.  More pushes than `cap` (never seen; forced by the test hook): every slice.
-__global__ __launch_bounds__(256) void quotient_fixup_kernel(QParams p, const u32 *redo, u32 cap, u32 total_blocks) {
-    extern __shared__ u64 sh[];
-    const u32 count = redo[0];
-    if (count == 0) return;
-    if (count <= cap) {
-        for (u32 k = blockIdx.x; k < count; k += gridDim.x) { quotient_block<1, true>(p, redo[1 + k], sh); __syncthreads(); }
-    } else {
-        for (u32 b = blockIdx.x; b < total_blocks; b += gridDim.x) { quotient_block<1, true>(p, b, sh); __syncthreads(); }
-    }
-}
-
 __global__ void canon_copy_kernel(const u64 *in, u64 *out, u32 n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl_canon(in[i]);
@@ -225,26 +212,18 @@ int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &c
     for (u32 i = 0; i < (1u << rate_bits); i++) p.zh_inv[i] = gl_inv(gl_sub(gl_mul(gn, gl_pow(wr, i)), 1));
     p.out = d_qcoeffs;
     const size_t shmem = (size_t)(air.host->n_regs ? air.host->n_regs : 1) * 256 * sizeof(u64);
-    const unsigned blocks = (unsigned)((L + 255) / 256);
     bool done = false;
     if (zk_quotient_jit_enabled(ctx, L)) {
-        const u32 cap = 1024;
-        u32 *redo = (u32 *)ctx->alloc((cap + 1) * sizeof(u32));
-        if (!redo) return ZK_ERR_OOM;
-        hipMemsetAsync(redo, 0, sizeof(u32), ctx->stream);
+        // compiled kernel for this program, if there is one (built with the library, or by hiprtc when that is switched on); a wave
+        // that skipped a rare repair redoes its points exactly inside the same kernel
         QJitParams jp = {};
         jp.trace_lde = p.trace_lde; jp.aux_lde = p.aux_lde; jp.pub = p.pub; jp.chal = p.chal; jp.alphas = p.alphas; jp.lag = p.lag;
         jp.xA = p.xA; jp.xB = p.xB; jp.out = p.out; jp.L = L; jp.last_inv = p.last_inv; jp.lgL = lgL;
-        jp.redo = redo; jp.redo_cap = cap; jp.force = (u32)ctx->force_redo;
+        jp.redo = nullptr; jp.redo_cap = 0; jp.force = ctx->force_redo ? 1u : 0u;
         for (int i = 0; i < 8; i++) jp.zh_inv[i] = p.zh_inv[i];
         rc = zk_quotient_jit_launch(ctx, air.host, p.C, p.A, nch, rate_bits, jp);
-        if (rc == ZK_OK) {
-            // slices in which the compiled kernel skipped a rare repair are recomputed by the interpreter (normally none or one)
-            ZK_LAUNCH(ctx, "quotient_fixup", quotient_fixup_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), shmem, p, (const u32 *)redo, cap, blocks);
-            done = true;
-        }
-        ctx->release(redo);
-        if (rc != ZK_OK && rc != ZK_JIT_UNAVAILABLE) return rc;
+        if (rc == ZK_OK) done = true;
+        else if (rc != ZK_JIT_UNAVAILABLE) return rc;
     }
     if (!done) ZK_LAUNCH(ctx, "quotient_eval", quotient_kernel, dim3((unsigned)((L + 511) / 512)), dim3(256), 2 * shmem, p, ctx->force_redo);
     // coset_ifft(g): leaf-order values -> natural-order coefficients, scaled by L^-1 g^-j.  In place.

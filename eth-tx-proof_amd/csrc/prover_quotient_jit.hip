@@ -103,16 +103,22 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, co
     s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
     s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
     appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
-    s += "    const u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);\n    const u64 z_last = gl_sub(x, p.last_inv);\n";
+    // The whole evaluation is one generic lambda instantiated twice: with glx<false> (products without the two 1-in-2^32 repairs,
+    // a wave-uniform sticky word instead) and, only in a wave whose word came back non-zero, again with glx<true>.  Same protocol as
+    // the hashing and NTT kernels; no list of flagged slices, no second kernel.  (The first version pushed flagged slice ids with
+    // an atomic at the very end of the kernel and had a fix-up kernel redo them: that variant ended in sporadic GPU memory faults
+    // that were never understood)
+    s += "    auto eval = [&](auto &g) {\n";
+    s += "    const u64 x = g.mul(p.xA[i & 2047], p.xB[i >> 11]);\n    const u64 z_last = gl_sub(x, p.last_inv);\n";
     s += "    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];\n";
-    s += "    glx<false> g; g.fl = 0;      // products without the two 1-in-2^32 repairs; a flagged slice is redone by the interpreter\n";
     for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = 0; const u64 al%u = p.alphas[%u];\n", j, j, j);
     for (u32 r = 0; r < air->n_regs; r++) appendf(s, "    u64 r%u = 0;\n", r);
     s += g.body;
     appendf(s, "    const u64 zi = p.zh_inv[i & %uu];\n", (1u << rate_bits) - 1);
     for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = g.mul(acc%u, zi);\n", j, j);
-    // p.force: test hook -- 1 flags every slice (the fix-up kernel then redoes all of them), 2 flags one slice in seven (the list path)
-    s += "    if ((g.fl != 0) | (p.force == 1u) | ((p.force == 2u) & ((blockIdx.x % 7u) == 3u))) {\n        if ((threadIdx.x & 63) == 0) { u32 k = atomicAdd(p.redo, 1u); if (k < p.redo_cap) p.redo[1 + k] = blockIdx.x; }\n    }\n";
+    s += "    };\n";
+    s += "    glx<false> gf; gf.fl = 0;\n    eval(gf);\n";
+    s += "    if ((gf.fl != 0) | p.force) { glx<true> ge; ge.fl = 0; eval(ge); }\n";
     s += "}\n";
     return s;
 }

@@ -206,11 +206,12 @@ def test_quotient_jit_equals_interpreter_and_oracle(zk, orc, monkeypatch, n_cols
     ref = orc.quotient(cfg, prog, ob, oab, pub, ch, al)
     # "2+forced redo": every slice flagged -> all redone by the interpreter fix-up; "0+prepared": kernels compiled ahead of
     # time by zk_prover_state_prepare (min size lowered so that these small tables qualify); "-": never (the default)
-    # "2+listed redo": one slice in seven flagged -> the fix-up kernel walks the list of flagged slices (what a real rare repair does)
-    for mode in ("2", "0", "2+forced redo", "2+listed redo", "0+prepared", "-"):
-        monkeypatch.setenv("ZK_QUOTIENT_JIT", "-1" if mode == "-" else mode[0])
+    # "2+forced redo": every wave takes the exact-redo branch of the compiled kernel
+    for mode in ("2", "0", "2+forced redo", "0+prepared", "-", "aot"):
+        monkeypatch.setenv("ZK_QUOTIENT_JIT", "-1" if mode in ("-", "aot") else mode[0])
         monkeypatch.setenv("ZK_QUOTIENT_JIT_MIN_LOG", "1")
-        monkeypatch.setenv("ZK_FORCE_EXACT_REDO", "1" if "forced" in mode else "2" if "listed" in mode else "0")
+        monkeypatch.setenv("ZK_FORCE_EXACT_REDO", "1" if "forced" in mode else "0")
+        monkeypatch.setenv("ZK_QUOTIENT_AOT", "1" if mode == "aot" else "0")     # "aot": kernels compiled with the library (93 x 19 shape)
         c2 = zk.Context(0)
         try:
             if "prepared" in mode:
