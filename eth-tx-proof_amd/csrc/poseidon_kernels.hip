@@ -110,7 +110,7 @@ template <bool EXACT> __device__ __forceinline__ u64 two_to_one_pair(const PsdmT
     pm.run(s);
     return pm.pc.fl;
 }
-__global__ __launch_bounds__(256, 2) void merkle_level_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ child, u64 *__restrict__ parent,
+__global__ __launch_bounds__(256, 3) void merkle_level_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ child, u64 *__restrict__ parent,
                                                                   size_t n_parents, u64 force_redo) {
     const u32 lane = threadIdx.x & 63;
     const size_t parent0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(size_t)63;   // n_parents is a multiple of 256
