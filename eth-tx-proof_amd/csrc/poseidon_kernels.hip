@@ -127,6 +127,47 @@ __global__ __launch_bounds__(256, 3) void merkle_level_mfma_kernel(const PsdmTab
         }
     }
 }
+// leaves of a FRI commit-phase layer: `arity` consecutive extension values flattened [a0,b0,a1,b1,...] from the re|im columns
+// (plonky2 0.2.2 fri::prover::fri_committed_trees; prover_fri.hip holds the one-thread-per-leaf version for small layers)
+template <bool EXACT> __device__ __forceinline__ u64 fri_leaf_sponge_pair(const PsdmTables *__restrict__ T, const u64 *__restrict__ re, const u64 *__restrict__ im,
+                                                                          u32 arity, size_t leaf0, u32 lane, const psdm_v4i *lds, u64 (&s)[2][6]) {
+    psdm::perm<EXACT> pm; pm.init(T, lane, lds);
+    const u32 n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) s[c][i] = 0;
+    for (u32 c0 = 0; c0 < arity; c0 += 4) {          // four extension values = eight sponge words per permutation
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const u32 w = 6 * h + i;
+            if (w < 8) {
+                const u64 *col = (w & 1) ? im : re;
+#pragma unroll
+                for (int c = 0; c < 2; c++) s[c][i] = col[(leaf0 + 32 * c + n) * arity + c0 + (w >> 1)];
+            }
+        }
+        pm.run(s);
+    }
+    return pm.pc.fl;
+}
+__global__ __launch_bounds__(256, 3) void fri_leaf_hash_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ re, const u64 *__restrict__ im,
+                                                                   size_t n_leaves, u32 arity, u64 *__restrict__ out, u64 force_redo) {
+    const u32 lane = threadIdx.x & 63;
+    const size_t leaf0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(size_t)63;     // n_leaves is a multiple of 256
+    __shared__ psdm_v4i shA[PSDM_LDS_V4];
+    psdm::lds_fill(T, shA); __syncthreads();
+    u64 s[2][6];
+    if (fri_leaf_sponge_pair<false>(T, re, im, arity, leaf0, lane, shA, s) | force_redo) fri_leaf_sponge_pair<true>(T, re, im, arity, leaf0, lane, shA, s);
+    if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            ulonglong2 *o = (ulonglong2 *)(out + 4 * (leaf0 + 32 * c + lane));
+            o[0] = make_ulonglong2(s[c][0], s[c][1]);
+            o[1] = make_ulonglong2(s[c][2], s[c][3]);
+        }
+    }
+}
 // device copy of the matrix-core tables: built on the host once per process, one copy per device shared by all contexts,
 // uploaded with a blocking hipMemcpy under a lock (complete before any launch that uses it can be enqueued)
 static const PsdmTables *psdm_tables(zk_ctx *ctx) {
@@ -280,6 +321,14 @@ int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uin
 int32_t zk_hash_leaves_rowmajor(zk_ctx *ctx, const u64 *rows, uint32_t leaf_len, size_t n_leaves, u64 *digests) {
     ZK_LAUNCH(ctx, "poseidon_leaf_hash_rows", hash_leaves_rowmajor_kernel, grid1(n_leaves), dim3(256), 0, rows, leaf_len, n_leaves, digests, 1, ctx->force_redo);
     return ZK_OK;
+}
+// true when the matrix-core kernel took the launch (big layers whose arity is a multiple of four); false: caller uses its own kernel
+bool zk_fri_leaf_hash_mfma(zk_ctx *ctx, const u64 *re, const u64 *im, size_t n_leaves, uint32_t arity, u64 *digests) {
+    if (!(ctx->poseidon_mfma & 1) || n_leaves < PSDM_MIN_UNITS || n_leaves % 256 != 0 || arity % 4 != 0 || arity * 2 <= 4) return false;
+    const PsdmTables *T = psdm_tables(ctx);
+    if (!T) return false;
+    ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_mfma_kernel, dim3((unsigned)(n_leaves / 256)), dim3(256), 0, T, re, im, n_leaves, arity, digests, ctx->force_redo);
+    return true;
 }
 int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap_height) {
     size_t cnt = n_leaves;

@@ -324,7 +324,8 @@ int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
         lvl[l] = (u64 *)ctx->alloc(n_dig * 4 * sizeof(u64));
         if (!lvl[l]) return ZK_ERR_OOM;
         owned[n_owned++] = lvl[l];
-        ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_kernel, g1(n_leaves), dim3(256), 0, vre[l], vim[l], n_leaves, arity, lvl[l], ctx->force_redo);
+        if (!zk_fri_leaf_hash_mfma(ctx, vre[l], vim[l], n_leaves, arity, lvl[l]))
+            ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_kernel, g1(n_leaves), dim3(256), 0, vre[l], vim[l], n_leaves, arity, lvl[l], ctx->force_redo);
         zk_merkle_levels(ctx, lvl[l], n_leaves, cfg.cap_height);
         const u64 *cap = lvl[l] + 4 * zk_level_offset(n_leaves, depth - cfg.cap_height);
         u64 *pcap = d_proof + lay.o_layer_caps + (size_t)l * capw;

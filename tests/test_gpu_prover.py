@@ -194,3 +194,22 @@ def test_mid_size_bit_exact(ctx, zk, orc):
     proof = zk.prove_tables(ctx, cfg, [(prog, 14, tr, pub)])
     rc, ref = orc.prove(cfg, [(prog, 14, tr, pub)])
     assert rc == 0 and (proof == ref).all()
+
+
+def test_2_17_rows_narrow_table_bit_exact_both_permutation_paths(zk, orc, monkeypatch):
+    """2^17 rows x 9 columns: the first FRI layer has 2^14 leaves, so the matrix-core FRI-leaf kernel, leaf kernel and Merkle-level kernel
+    all take part (and, with ZK_POSEIDON_MFMA=0, none of them); both proofs must equal the oracle's word for word."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(9, 3)
+    tr, pub = orc.synth_trace(9, 17, 99)
+    rc, ref = orc.prove(cfg, [(prog, 17, tr, pub)])
+    assert rc == 0
+    for mode in ("3", "0"):
+        monkeypatch.setenv("ZK_POSEIDON_MFMA", mode)
+        c = zk.Context(0)
+        try:
+            proof = zk.prove_tables(c, cfg, [(prog, 17, tr, pub)])
+            assert (proof == ref).all(), mode
+        finally:
+            c.close()
