@@ -170,11 +170,8 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
         if (const void *fn = zk_quotient_aot_lookup(fnv1a(air_key(air, C, A, nch, rate_bits)))) {
             void *args[] = {&p};
             hipError_t e;
-            // ZK_DEBUG_QSYNC (default 2): bit 0 = wait for the stream before the launch, bit 1 = after it.  Without the wait AFTER
-            // the compiled kernel, a 2^20-row proof faults deterministically ("memory access fault by GPU", tools/prove_twice.py 20)
-            // although neither this kernel nor the kernels enqueued behind it form an address from data; with it, never.  The wait
-            // before it changes nothing.  Not understood; the wait costs one host round trip per table.
-            static const int qsync = getenv("ZK_DEBUG_QSYNC") ? atoi(getenv("ZK_DEBUG_QSYNC")) : 2;
+            // ZK_DEBUG_QSYNC (debugging aid, default 0): bit 0 = wait for the stream before the launch, bit 1 = after it
+            static const int qsync = getenv("ZK_DEBUG_QSYNC") ? atoi(getenv("ZK_DEBUG_QSYNC")) : 0;
             if (qsync & 1) hipStreamSynchronize(ctx->stream);
             { ProfScope ps(ctx, "quotient_eval"); e = hipLaunchKernel(fn, dim3((unsigned)((p.L + 255) / 256)), dim3(256), args, 0, ctx->stream); }
             if (qsync & 2) hipStreamSynchronize(ctx->stream);
