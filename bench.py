@@ -216,8 +216,8 @@ def main():
             per_launch = ab * proofs0 / dlaunch                    # algorithmic bytes per launch
             achieved = per_launch / (dms / dlaunch * 1e-3) / 1e9   # GB/s
         traffic, pm = None, None
-        try:   # HBM bytes and instruction mix from the committed rocprofv3 PMC passes (profiles/r01f_pmc_leaf_hash.json)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_leaf_hash.json")))["leaf_hash_93cols"]
+        try:   # HBM bytes and instruction mix from the committed rocprofv3 PMC passes (profiles/r01g_pmc_leaf_hash.json)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_leaf_hash.json")))["leaf_hash_93cols"]
             if dname == "poseidon_leaf_hash" and per_launch:
                 traffic = per_launch * pm["pmc_bytes"] / pm["algorithmic_bytes"]
         except Exception:
@@ -231,7 +231,7 @@ def main():
                    "valu_instr_per_wave_of_64_permutations": vw,
                    "mfma_i8_instr_per_wave_of_64_permutations": pm["mfma_i8_instr_per_wave_permutation"] if pm else None,
                    "valu_issue_bound_permutations_per_s": (1024 * 2.1e9 / (4.0 * vw) * 64) if vw else None,
-                   "note": "SQ counters (profiles/r01f_pmc_summary_commit_bench.json): the linear layers run on the i8 matrix cores "
+                   "note": "SQ counters (profiles/r01g_pmc_summary_commit_bench.json): the linear layers run on the i8 matrix cores "
                            "(234 v_mfma_i32_32x32x32_i8 per 64 permutations), the s-boxes and limb recombination on the vector ALU; "
                            "the bound quoted is 1024 SIMDs x ~2.1 GHz / (4 cycles x VALU instructions per 64-permutation wave)"}
         roof = {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
