@@ -206,6 +206,7 @@ extern "C" int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *c
         const size_t L = (size_t)1 << (tables[t].log_n + cfg->rate_bits);
         if (!zk_quotient_jit_enabled(ctx, L)) continue;
         const u32 nch = cfg->num_challenges, A = air->n_helpers ? nch * (air->n_helpers + 1) : 0;
+        if (ctx->quotient_aot && zk_quotient_aot_lookup(fnv1a(air_key(air, air->n_trace_cols, A, nch, cfg->rate_bits)))) continue;   // built with the library
         JitKernel k;
         int32_t rc = jit_get(ctx, air, air->n_trace_cols, A, nch, cfg->rate_bits, true, k);
         if (rc != ZK_OK) return rc;
