@@ -213,3 +213,40 @@ def test_2_17_rows_narrow_table_bit_exact_both_permutation_paths(zk, orc, monkey
             assert (proof == ref).all(), mode
         finally:
             c.close()
+
+
+def test_four_streams_full_size_units_equal_their_single_stream_proofs(zk, orc):
+    """bench.py's shape as a test: four contexts (= four HIP streams), one host thread each, proving 2^20-row units concurrently, twice.
+    Every proof must equal the proof of the same unit made alone, and verify.  (An earlier generation of the compiled constraint
+    kernels ended in GPU memory faults in exactly this setting and nowhere in the test-suite: DESIGN.md section 9.)"""
+    import threading
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(93, 19)
+    log_n, T = 20, 4
+    ctxs = [zk.Context(0) for _ in range(T)]
+    try:
+        units = [zk.synth_trace_dev(ctxs[i], 93, log_n, 0x5EED0000 + 1000 * i) for i in range(T)]
+        alone = [zk.prove_tables(ctxs[0], cfg, [(prog, log_n, units[i][0], units[i][1])]).copy() for i in range(T)]
+        for c in ctxs:
+            c.synchronize()
+        got, errs = {}, []
+
+        def work(i, r):
+            try:
+                got[(i, r)] = zk.prove_tables(ctxs[i], cfg, [(prog, log_n, units[i][0], units[i][1])]).copy()
+            except Exception as e:      # surfaced after join
+                errs.append(e)
+        for r in range(2):
+            th = [threading.Thread(target=work, args=(i, r)) for i in range(T)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        assert not errs, errs
+        for (i, r), p in got.items():
+            assert (p == alone[i]).all(), (i, r)
+        assert orc.verify(cfg, [(prog, log_n, None, units[0][1])], alone[0]) == 0
+    finally:
+        for c in ctxs:
+            c.close()
