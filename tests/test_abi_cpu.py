@@ -58,3 +58,26 @@ def test_cpp_operator_mirror_builds_and_fails_loudly_without_gpu(zk, tmp_path):
         assert rc.returncode == 1 and "FatalError" in rc.stdout
     else:
         assert rc.returncode == 0, rc.stdout
+
+
+def test_build_time_constraint_kernels_are_what_the_generator_emits(zk):
+    """csrc/prover_quotient_aot.hip (compiled with the library) must hold, verbatim, the kernel source the library's own generator
+    (zk_quotient_kernel_source, host only) emits for each build-time AIR shape -- so build-time and hiprtc kernels cannot drift apart,
+    and a change of the generator without `python tools/gen_aot_quotient.py` is caught here."""
+    import os
+    from eth_tx_proof_amd import air
+    L = zk.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "eth-tx-proof_amd", "csrc", "prover_quotient_aot.hip")).read()
+    prog = air.cpu_like_air(93, 19, 2)
+    ln, h = C.c_size_t(0), C.c_uint64(0)
+    assert L.zk_quotient_kernel_source(prog.ref, C.c_uint32(2), C.c_uint32(1), None, C.c_size_t(0), C.byref(ln), C.byref(h)) == 0
+    buf = C.create_string_buffer(ln.value + 1)
+    assert L.zk_quotient_kernel_source(prog.ref, C.c_uint32(2), C.c_uint32(1), buf, C.c_size_t(ln.value + 1), C.byref(ln), C.byref(h)) == 0
+    src = buf.value.decode()
+    assert "quotient_aot_%016x" % h.value in src
+    assert src in text
+    assert "0x%016xULL" % h.value in text           # registry entry
+    # too small a buffer is refused, not overrun
+    small = C.create_string_buffer(16)
+    assert L.zk_quotient_kernel_source(prog.ref, C.c_uint32(2), C.c_uint32(1), small, C.c_size_t(16), C.byref(ln), C.byref(h)) != 0
