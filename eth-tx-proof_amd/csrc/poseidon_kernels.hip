@@ -308,14 +308,18 @@ __global__ void digests_layout_kernel(const u64 *levels, size_t n_leaves, u32 n_
 static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uint32_t n_cols, size_t n_leaves, u64 *digests) {
+    // one profiler label per launch shape (the sponge length is what a launch costs): poseidon_leaf_hash_c93, .._c40, and
+    // poseidon_leaf_copy_c4 for the hash_or_noop copy branch, so that an average launch duration means one thing
+    char label[48];
+    snprintf(label, sizeof label, n_cols > 4 ? "poseidon_leaf_hash_c%u" : "poseidon_leaf_copy_c%u", n_cols);
     if ((ctx->poseidon_mfma & 1) && n_cols > 4 && n_leaves >= PSDM_MIN_UNITS && n_leaves % 256 == 0) {
         const PsdmTables *T = psdm_tables(ctx);
         if (!T) return ZK_ERR_OOM;
-        ZK_LAUNCH(ctx, "poseidon_leaf_hash", hash_leaves_colmajor_mfma_kernel, dim3((unsigned)(n_leaves / 256)), dim3(256), 0, T, cols, stride, n_cols,
+        ZK_LAUNCH(ctx, label, hash_leaves_colmajor_mfma_kernel, dim3((unsigned)(n_leaves / 256)), dim3(256), 0, T, cols, stride, n_cols,
                   n_leaves, digests, ctx->force_redo);
         return ZK_OK;
     }
-    ZK_LAUNCH(ctx, "poseidon_leaf_hash", hash_leaves_colmajor_kernel, grid1(n_leaves), dim3(256), 0, cols, stride, n_cols, n_leaves, digests, ctx->force_redo);
+    ZK_LAUNCH(ctx, label, hash_leaves_colmajor_kernel, grid1(n_leaves), dim3(256), 0, cols, stride, n_cols, n_leaves, digests, ctx->force_redo);
     return ZK_OK;
 }
 int32_t zk_hash_leaves_rowmajor(zk_ctx *ctx, const u64 *rows, uint32_t leaf_len, size_t n_leaves, u64 *digests) {

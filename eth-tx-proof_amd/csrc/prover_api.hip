@@ -12,9 +12,44 @@ static u32 n_aux_of(const zk_air *air, u32 nch) { return air->n_helpers ? nch * 
 
 extern "C" {
 
+int32_t zk_air_validate(const zk_air *air, uint32_t nch) {
+    if (!air || nch == 0 || nch > 4) return ZK_ERR_INVALID_ARG;
+    if (air->n_trace_cols == 0 || air->n_trace_cols > (1u << 20) || air->n_helpers > (1u << 16) || air->n_regs > (1u << 16) ||
+        air->n_instrs > (1u << 24) || air->n_constants > (1u << 24) || air->n_public_inputs > (1u << 24))
+        return ZK_ERR_INVALID_ARG;
+    if ((air->n_instrs && !air->instrs) || (air->n_constants && !air->constants) || (air->n_helpers && !air->helpers)) return ZK_ERR_INVALID_ARG;
+    const u32 C = air->n_trace_cols, A = n_aux_of(air, nch);
+    for (u32 m = 0; m < air->n_helpers; m++) {
+        const zk_helper_desc &h = air->helpers[m];
+        if (h.a0 >= C || h.b0 >= C || h.a1 >= C || h.b1 >= C) return ZK_ERR_INVALID_ARG;
+    }
+    auto src_ok = [&](u32 o) {
+        const u32 kind = o >> 24, idx = o & 0xFFFFFFu;
+        switch (kind) {
+        case ZK_OPND_REG: return idx < air->n_regs;
+        case ZK_OPND_LOCAL: case ZK_OPND_NEXT: return idx < C + A;
+        case ZK_OPND_CONST: return idx < air->n_constants;
+        case ZK_OPND_PUBLIC: return idx < air->n_public_inputs;
+        case ZK_OPND_CHALLENGE: return idx < 2 * nch;
+        default: return false;
+        }
+    };
+    for (u32 i = 0; i < air->n_instrs; i++) {
+        const zk_instr &in = air->instrs[i];
+        if (in.op > ZK_OP_EMIT_LAST) return ZK_ERR_INVALID_ARG;
+        if (!src_ok(in.a)) return ZK_ERR_INVALID_ARG;
+        if (in.op <= ZK_OP_MUL) {                                  // dst = a (op) b; dst is a plain register number
+            if (!src_ok(in.b)) return ZK_ERR_INVALID_ARG;
+            if ((in.dst >> 24) != ZK_OPND_REG || (in.dst & 0xFFFFFFu) >= air->n_regs) return ZK_ERR_INVALID_ARG;
+        }
+    }
+    return ZK_OK;
+}
+
 int32_t zk_aux_columns(zk_ctx *ctx, const zk_air *air, uint32_t num_challenges, const uint64_t *challenges,
                        const uint64_t *trace, uint32_t log_n, uint64_t *aux_out) {
     if (!ctx || !air || !challenges || !trace || !aux_out || num_challenges == 0 || num_challenges > 4 || log_n > 26) return ZK_ERR_INVALID_ARG;
+    if (zk_air_validate(air, num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "aux_columns: malformed AIR");
     hipSetDevice(ctx->device);
     const u32 A = n_aux_of(air, num_challenges);
     if (!A) return ZK_OK;
@@ -42,6 +77,13 @@ int32_t zk_quotient(zk_ctx *ctx, const zk_stark_config *cfg, const zk_air *air, 
                     const uint64_t *public_inputs, const uint64_t *challenges, const uint64_t *alphas, uint64_t *quotient_coeffs_out) {
     if (!ctx || !cfg || !air || !trace || !alphas || !quotient_coeffs_out) return ZK_ERR_INVALID_ARG;
     if (trace->n_cols != air->n_trace_cols || (aux && aux->log_n != trace->log_n)) return ZK_ERR_INVALID_ARG;
+    if (zk_air_validate(air, cfg->num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: malformed AIR");
+    {   // the auxiliary batch must hold exactly the columns the program may address
+        const u32 A = n_aux_of(air, cfg->num_challenges);
+        if ((A != 0) != (aux != nullptr) || (aux && aux->n_cols != A)) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: auxiliary batch does not match the AIR");
+        if (A && !challenges) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: challenges missing");
+        if (air->n_public_inputs && !public_inputs) return ctx->fail(ZK_ERR_INVALID_ARG, "quotient: public inputs missing");
+    }
     hipSetDevice(ctx->device);
     const u32 nch = cfg->num_challenges;
     const size_t L = trace->L();
@@ -167,7 +209,7 @@ int32_t zk_fri_prove_instance(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t 
                               const zk_fri_batch *batches, zk_challenger *ch, uint64_t *fri_proof_out, size_t cap_words, size_t *len_words) {
     if (!ctx || !cfg || !oracles || !batches || !ch || !fri_proof_out || ch->ctx != ctx) return ZK_ERR_INVALID_ARG;
     if (n_oracles == 0 || n_oracles > 8 || n_batches == 0 || n_batches > 4) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: 1..8 oracles, 1..4 batches");
-    if (cfg->rate_bits > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits == 0 || cfg->fri_arity_bits > 6 || cfg->num_query_rounds == 0 ||
+    if (cfg->rate_bits > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits < 2 || cfg->fri_arity_bits > 6 || cfg->num_query_rounds == 0 ||
         cfg->proof_of_work_bits > 34)
         return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: unsupported FRI parameters");
     u32 ncols[8];

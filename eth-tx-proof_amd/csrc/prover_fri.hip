@@ -253,13 +253,14 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     int32_t rc = ZK_OK;
 
     // ---- alpha, alpha powers, reduced openings
-    u64 *d_alpha = (u64 *)ctx->alloc(2 * sizeof(u64));
+    ZkOwned own(ctx);                       // every exit path hands the scratch blocks back
+    u64 *d_alpha = (u64 *)own.get(2 * sizeof(u64));
     u32 cnt = C + A + Q;
-    u64 *d_apow = (u64 *)ctx->alloc((size_t)(cnt + 2) * 2 * sizeof(u64));
-    u64 *d_y = (u64 *)ctx->alloc(6 * sizeof(u64));
-    u64 *P = (u64 *)ctx->alloc(6 * n * sizeof(u64)), *Pval = (u64 *)ctx->alloc(6 * L * sizeof(u64)), *tmp = (u64 *)ctx->alloc(6 * n * sizeof(u64));
-    u64 *F = (u64 *)ctx->alloc(2 * L * sizeof(u64));
-    if (!d_alpha || !d_apow || !d_y || !P || !Pval || !tmp || !F) return ZK_ERR_OOM;
+    u64 *d_apow = (u64 *)own.get((size_t)(cnt + 2) * 2 * sizeof(u64));
+    u64 *d_y = (u64 *)own.get(6 * sizeof(u64));
+    u64 *P = (u64 *)own.get(6 * n * sizeof(u64)), *Pval = (u64 *)own.get(6 * L * sizeof(u64)), *tmp = (u64 *)own.get(6 * n * sizeof(u64));
+    u64 *F = (u64 *)own.get(2 * L * sizeof(u64));
+    if (!d_alpha || !d_apow || !d_y || !P || !Pval || !tmp || !F) return ctx->fail(ZK_ERR_OOM, "fri: out of device memory");
     { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_alpha; a.op[0].n = 2; zk_transcript_run(ctx, ch, a); }
     ZK_LAUNCH(ctx, "fri_alpha_pows", alpha_pows_kernel, g1(cnt + 2), dim3(256), 0, (const u64 *)d_alpha, cnt, C + A, nch, d_apow);
     ZK_LAUNCH(ctx, "fri_reduce_openings", reduce_openings_kernel, dim3(nb), dim3(256), 0, (const u64 *)d_proof, lay, C, A, Q, nch, (const u64 *)d_apow, d_y);
@@ -280,13 +281,11 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
     qp.xA = xs.A; qp.xB = xs.B; qp.pts = d_zeta; qp.y = d_y; qp.shifts = d_apow + 2 * cnt; qp.F = F;
     ZK_LAUNCH(ctx, "fri_quotient", fri_quotient_kernel, g1(L), dim3(256), 0, qp);
-    ctx->release(d_alpha); ctx->release(d_apow); ctx->release(d_y); ctx->release(P); ctx->release(Pval); ctx->release(tmp);
+    own.drop(d_alpha); own.drop(d_apow); own.drop(d_y); own.drop(P); own.drop(Pval); own.drop(tmp);   // reusable by the commit phase
 
     const zk_batch *oracles[3]; u32 no = 0;
     oracles[no++] = trace; if (A) oracles[no++] = aux; oracles[no++] = quot;
-    rc = zk_fri_proof_dev(ctx, cfg, ch, log_n, F, oracles, no, d_proof, lay);
-    ctx->release(F);
-    return rc;
+    return zk_fri_proof_dev(ctx, cfg, ch, log_n, F, oracles, no, d_proof, lay);
 }
 
 // plonky2::fri::prover::fri_proof on the final values F (re | im columns of L, leaf order): commit phase, PoW, query rounds
@@ -298,8 +297,9 @@ int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     u32 ar[64], nl; zk_fri_arities(cfg, log_n, ar, &nl);
     if (nl > 8 || n_oracles > 8) return ctx->fail(ZK_ERR_INVALID_ARG, "fri: more than 8 reduction layers or oracles");
     int32_t rc = ZK_OK;
-    u64 *Fco = (u64 *)ctx->alloc(2 * L * sizeof(u64));
-    if (!Fco) return ZK_ERR_OOM;
+    ZkOwned own(ctx);
+    u64 *Fco = (u64 *)own.get(2 * L * sizeof(u64));
+    if (!Fco) return ctx->fail(ZK_ERR_OOM, "fri: out of device memory");
     // ---- lde_final_poly coefficients (natural order): coset_ifft(g) of the final values
     {
         TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);
@@ -309,21 +309,20 @@ int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
 
     // ---- fri_committed_trees
     ZK_LAUNCH(ctx, "write_word", write_word_kernel, dim3(1), dim3(1), 0, d_proof + lay.o_nl, (u64)nl);
-    const u64 *vre[9], *vim[9]; u64 *lvl[8]; u64 *owned[40]; int n_owned = 0;
+    const u64 *vre[9], *vim[9]; u64 *lvl[8];
     vre[0] = F; vim[0] = F + L;
     u64 *cre = Fco, *cim = Fco + L;          // current coefficients (natural order)
     size_t cur = L; u32 cur_lg = lgL;
     u64 shift = GL_GEN;
-    u64 *d_beta = (u64 *)ctx->alloc(2 * 8 * sizeof(u64));
-    if (!d_beta) return ZK_ERR_OOM;
+    u64 *d_beta = (u64 *)own.get(2 * 8 * sizeof(u64));
+    if (!d_beta) return ctx->fail(ZK_ERR_OOM, "fri: out of device memory");
     for (u32 l = 0; l < nl; l++) {
         u32 arity = 1u << ar[l];
         size_t n_leaves = cur >> ar[l];
         u32 depth = cur_lg - ar[l];
         size_t n_dig = zk_level_offset(n_leaves, depth - cfg.cap_height + 1);
-        lvl[l] = (u64 *)ctx->alloc(n_dig * 4 * sizeof(u64));
-        if (!lvl[l]) return ZK_ERR_OOM;
-        owned[n_owned++] = lvl[l];
+        lvl[l] = (u64 *)own.get(n_dig * 4 * sizeof(u64));
+        if (!lvl[l]) return ctx->fail(ZK_ERR_OOM, "fri: out of device memory");
         if (!zk_fri_leaf_hash_mfma(ctx, vre[l], vim[l], n_leaves, arity, lvl[l]))
             ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_kernel, g1(n_leaves), dim3(256), 0, vre[l], vim[l], n_leaves, arity, lvl[l], ctx->force_redo);
         zk_merkle_levels(ctx, lvl[l], n_leaves, cfg.cap_height);
@@ -333,9 +332,8 @@ int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
         { TOpList a = {}; a.n = 2; a.op[0].kind = TOP_OBSERVE; a.op[0].src = pcap; a.op[0].n = capw;
           a.op[1].kind = TOP_GET; a.op[1].dst = d_beta + 2 * l; a.op[1].n = 2; zk_transcript_run(ctx, ch, a); }
         size_t nxt = cur >> ar[l];
-        u64 *nco = (u64 *)ctx->alloc(2 * nxt * sizeof(u64)), *nva = (u64 *)ctx->alloc(2 * nxt * sizeof(u64));
-        if (!nco || !nva) return ZK_ERR_OOM;
-        owned[n_owned++] = nco; owned[n_owned++] = nva;
+        u64 *nco = (u64 *)own.get(2 * nxt * sizeof(u64)), *nva = (u64 *)own.get(2 * nxt * sizeof(u64));
+        if (!nco || !nva) return ctx->fail(ZK_ERR_OOM, "fri: out of device memory");
         ZK_LAUNCH(ctx, "fri_fold", fri_fold_kernel, g1(nxt), dim3(256), 0, (const u64 *)cre, (const u64 *)cim, nxt, arity, (const u64 *)(d_beta + 2 * l), nco, nco + nxt);
         cre = nco; cim = nco + nxt;
         shift = gl_pow(shift, arity);
@@ -352,8 +350,8 @@ int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + lay.o_final; a.op[0].n = 2 * flen; zk_transcript_run(ctx, ch, a); }
 
     // ---- proof of work, query indices
-    u64 *d_pow = (u64 *)ctx->alloc(16 * sizeof(u64)), *d_idx = (u64 *)ctx->alloc((size_t)cfg.num_query_rounds * sizeof(u64));
-    if (!d_pow || !d_idx) return ZK_ERR_OOM;
+    u64 *d_pow = (u64 *)own.get(16 * sizeof(u64)), *d_idx = (u64 *)own.get((size_t)cfg.num_query_rounds * sizeof(u64));
+    if (!d_pow || !d_idx) return ctx->fail(ZK_ERR_OOM, "fri: out of device memory");
     zk_pow_grind_dev(ctx, ch, cfg.proof_of_work_bits, d_pow, d_proof + lay.o_witness);
     { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET_INDICES; a.op[0].dst = d_idx; a.op[0].n = cfg.num_query_rounds; a.op[0].aux = lgL; zk_transcript_run(ctx, ch, a); }
 
@@ -365,8 +363,6 @@ int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     q.idx = d_idx; q.out = d_proof + lay.o_queries; q.per_query = lay.per_query;
     ZK_LAUNCH(ctx, "fri_query_gather", fri_query_kernel, dim3(cfg.num_query_rounds), dim3(256), 0, q);
 
-    for (int i = 0; i < n_owned; i++) ctx->release(owned[i]);
-    ctx->release(Fco); ctx->release(d_beta); ctx->release(d_pow); ctx->release(d_idx);
     return ZK_OK;
 }
 
@@ -491,14 +487,15 @@ int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevCh
         if (oracles[o]->log_n != log_n || oracles[o]->rate_bits != rate_bits || oracles[o]->cap_height != cfg.cap_height)
             return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: oracles must share log_n and the config's rate_bits / cap_height");
     int32_t rc = ZK_OK;
-    u64 *d_alpha = (u64 *)ctx->alloc(2 * sizeof(u64));
-    u64 *d_apow = (u64 *)ctx->alloc((size_t)(gp.cnt + FRI_MAX_BATCHES) * 2 * sizeof(u64));
-    u64 *d_pts = (u64 *)ctx->alloc(2 * FRI_MAX_BATCHES * sizeof(u64)), *d_ev = (u64 *)ctx->alloc(4 * FRI_MAX_BATCHES * sizeof(u64));
-    u64 *d_y = (u64 *)ctx->alloc(2 * FRI_MAX_BATCHES * sizeof(u64));
-    const u64 **d_cols = (const u64 **)ctx->alloc(cols.size() * sizeof(u64 *));
-    u64 *P = (u64 *)ctx->alloc(2 * nb * n * sizeof(u64)), *Pval = (u64 *)ctx->alloc(2 * nb * L * sizeof(u64)), *tmp = (u64 *)ctx->alloc(2 * nb * n * sizeof(u64));
-    u64 *F = (u64 *)ctx->alloc(2 * L * sizeof(u64));
-    if (!d_alpha || !d_apow || !d_pts || !d_ev || !d_y || !d_cols || !P || !Pval || !tmp || !F) return ZK_ERR_OOM;
+    ZkOwned own(ctx);
+    u64 *d_alpha = (u64 *)own.get(2 * sizeof(u64));
+    u64 *d_apow = (u64 *)own.get((size_t)(gp.cnt + FRI_MAX_BATCHES) * 2 * sizeof(u64));
+    u64 *d_pts = (u64 *)own.get(2 * FRI_MAX_BATCHES * sizeof(u64)), *d_ev = (u64 *)own.get(4 * FRI_MAX_BATCHES * sizeof(u64));
+    u64 *d_y = (u64 *)own.get(2 * FRI_MAX_BATCHES * sizeof(u64));
+    const u64 **d_cols = (const u64 **)own.get(cols.size() * sizeof(u64 *));
+    u64 *P = (u64 *)own.get(2 * nb * n * sizeof(u64)), *Pval = (u64 *)own.get(2 * nb * L * sizeof(u64)), *tmp = (u64 *)own.get(2 * nb * n * sizeof(u64));
+    u64 *F = (u64 *)own.get(2 * L * sizeof(u64));
+    if (!d_alpha || !d_apow || !d_pts || !d_ev || !d_y || !d_cols || !P || !Pval || !tmp || !F) return ctx->fail(ZK_ERR_OOM, "fri instance: out of device memory");
     rc = zk_dev_upload(ctx, d_pts, hpts, sizeof hpts);
     if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_cols, cols.data(), cols.size() * sizeof(u64 *));
     if (rc) return rc;
@@ -521,9 +518,7 @@ int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevCh
     TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
     qp.xA = xs.A; qp.xB = xs.B; qp.pts = d_pts; qp.y = d_y; qp.shifts = d_apow + 2 * gp.cnt; qp.F = F;
     ZK_LAUNCH(ctx, "fri_quotient", fri_quotient_gen_kernel, g1(L), dim3(256), 0, qp);
-    ctx->release(d_alpha); ctx->release(d_apow); ctx->release(d_pts); ctx->release(d_ev); ctx->release(d_y); ctx->release((void *)d_cols);
-    ctx->release(P); ctx->release(Pval); ctx->release(tmp);
-    rc = zk_fri_proof_dev(ctx, cfg, ch, log_n, F, oracles, n_oracles, d_proof, lay);
-    ctx->release(F);
-    return rc;
+    own.drop(d_alpha); own.drop(d_apow); own.drop(d_pts); own.drop(d_ev); own.drop(d_y); own.drop((void *)d_cols);
+    own.drop(P); own.drop(Pval); own.drop(tmp);
+    return zk_fri_proof_dev(ctx, cfg, ch, log_n, F, oracles, n_oracles, d_proof, lay);
 }

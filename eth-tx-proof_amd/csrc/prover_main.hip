@@ -93,11 +93,13 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
                                  uint64_t *proof_out, size_t cap_words, size_t *len_words) {
     if (!ctx || !cfgp || !tables || nt == 0 || !proof_out) return ZK_ERR_INVALID_ARG;
     const zk_stark_config &cfg = *cfgp;
-    if (cfg.num_challenges == 0 || cfg.num_challenges > 4 || cfg.rate_bits != 1 || cfg.cap_height > 8 || cfg.fri_arity_bits == 0 || cfg.fri_arity_bits > 6)
+    if (cfg.num_challenges == 0 || cfg.num_challenges > 4 || cfg.rate_bits != 1 || cfg.cap_height > 8 || cfg.fri_arity_bits < 2 || cfg.fri_arity_bits > 6)
         return ctx->fail(ZK_ERR_INVALID_ARG, "prove: unsupported StarkConfig");
     for (u32 t = 0; t < nt; t++) {
         if (!tables[t].air || !tables[t].trace || tables[t].log_n > 26 || tables[t].log_n + cfg.rate_bits < cfg.cap_height)
             return ctx->fail(ZK_ERR_INVALID_ARG, "prove: bad table");
+        if (zk_air_validate(tables[t].air, cfg.num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: malformed AIR (zk_air_validate)");
+        if (tables[t].air->n_public_inputs && !tables[t].public_inputs) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: public inputs missing");
     }
     hipSetDevice(ctx->device);
     const u32 nch = cfg.num_challenges, capw = 4u << cfg.cap_height;
@@ -108,12 +110,24 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
     if (cap_words < total) return ctx->fail(ZK_ERR_BUFFER_TOO_SMALL, "prove: proof buffer too small");
 
     int32_t rc = ZK_OK;
-    std::vector<void *> owned;                       // released at the end (stream-ordered)
+    // Everything this proof allocates is handed back on EVERY exit path, and only after the stream has drained: an early return
+    // must not let the next proof of this context reuse pinned staging or scratch that an enqueued copy or kernel still reads.
+    struct Guard {
+        zk_ctx *ctx; std::vector<void *> owned; std::vector<zk_batch *> trace_b, aux_b, quot_b;
+        ~Guard() {
+            hipStreamSynchronize(ctx->stream);
+            for (auto *b : trace_b) if (b) zk_batch_free(b);
+            for (auto *b : aux_b) if (b) zk_batch_free(b);
+            for (auto *b : quot_b) if (b) zk_batch_free(b);
+            for (void *q : owned) ctx->release(q);
+        }
+    } guard{ctx, {}, std::vector<zk_batch *>(nt, nullptr), std::vector<zk_batch *>(nt, nullptr), std::vector<zk_batch *>(nt, nullptr)};
+    std::vector<void *> &owned = guard.owned;
     auto A_ = [&](size_t bytes) { void *p = ctx->alloc(bytes); if (p) owned.push_back(p); return p; };
     u64 *d_proof = (u64 *)A_(total * sizeof(u64));
     DevChallenger *ch = (DevChallenger *)A_(sizeof(DevChallenger));
     u64 *d_chal = (u64 *)A_(16 * sizeof(u64)), *d_alphas = (u64 *)A_(8 * sizeof(u64)), *d_zeta = (u64 *)A_(8 * sizeof(u64));
-    if (!d_proof || !ch || !d_chal || !d_alphas || !d_zeta) return ZK_ERR_OOM;
+    if (!d_proof || !ch || !d_chal || !d_alphas || !d_zeta) return ctx->fail(ZK_ERR_OOM, "prove: out of device memory");
 
     // small host objects go up through the context's pinned staging (zk_ctx::upload_small); the proof comes back through
     // its pinned download buffer.  The staging is reused from the start: the previous proof of this context has been waited for.
@@ -155,12 +169,8 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         }
     }
 
-    std::vector<zk_batch *> trace_b(nt, nullptr), aux_b(nt, nullptr), quot_b(nt, nullptr);
+    std::vector<zk_batch *> &trace_b = guard.trace_b, &aux_b = guard.aux_b, &quot_b = guard.quot_b;
     std::vector<const u64 *> d_trace(nt, nullptr);
-    auto cleanup = [&]() {
-        for (u32 t = 0; t < nt; t++) { if (trace_b[t]) zk_batch_free(trace_b[t]); if (aux_b[t]) zk_batch_free(aux_b[t]); if (quot_b[t]) zk_batch_free(quot_b[t]); }
-        for (void *p : owned) ctx->release(p);
-    };
 
     // ---- commit every trace; observe every trace cap, then the public values; draw the lookup/CTL challenges
     { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_INIT; zk_transcript_run(ctx, ch, a); }
@@ -182,7 +192,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + lay[t].o_trace_cap; a.op[0].n = capw;
         zk_transcript_run(ctx, ch, a);
     }
-    if (rc) { hipStreamSynchronize(ctx->stream); cleanup(); return rc; }
+    if (rc) return rc;
     for (u32 t = 0; t < nt; t++) if (tables[t].air->n_public_inputs) {
         TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_pub[t]; a.op[0].n = tables[t].air->n_public_inputs;
         zk_transcript_run(ctx, ch, a);
@@ -263,6 +273,5 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         ctx->fail(rc, "prove: device-side check failed");
         hipMemsetAsync(ctx->d_err, 0, sizeof(u64), ctx->stream);
     }
-    cleanup();
     return rc;
 }

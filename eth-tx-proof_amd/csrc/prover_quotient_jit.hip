@@ -145,6 +145,7 @@ const void *zk_quotient_aot_lookup(u64 key_hash);
 extern "C" int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_challenges, uint32_t rate_bits, char *buf, size_t cap,
                                              size_t *len, uint64_t *key_hash) {
     if (!air || !len || !key_hash) return ZK_ERR_INVALID_ARG;
+    if (zk_air_validate(air, num_challenges) != ZK_OK) return ZK_ERR_INVALID_ARG;      // the generator indexes by operand
     const u32 A = air->n_helpers ? num_challenges * (air->n_helpers + 1) : 0;
     const u64 h = fnv1a(air_key(air, air->n_trace_cols, A, num_challenges, rate_bits));
     char name[64]; snprintf(name, sizeof name, "quotient_aot_%016llx", (unsigned long long)h);
@@ -203,6 +204,7 @@ extern "C" int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *c
     for (uint32_t t = 0; t < n_tables; t++) {
         const zk_air *air = tables[t].air;
         if (!air) return ZK_ERR_INVALID_ARG;
+        if (zk_air_validate(air, cfg->num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "prover_state_prepare: malformed AIR");
         const size_t L = (size_t)1 << (tables[t].log_n + cfg->rate_bits);
         if (!zk_quotient_jit_enabled(ctx, L)) continue;
         const u32 nch = cfg->num_challenges, A = air->n_helpers ? nch * (air->n_helpers + 1) : 0;

@@ -175,6 +175,13 @@ typedef struct {
     const zk_instr *instrs;
 } zk_air;
 
+/* Structural check of a constraint program: every opcode known, destinations are registers below n_regs, LOCAL/NEXT indices
+ * below n_trace_cols + auxiliary columns, CONST / PUBLIC / CHALLENGE indices inside their arrays (2 * num_challenges challenge
+ * words), helper descriptors name trace columns.  ZK_OK or ZK_ERR_INVALID_ARG.  Every entry point that takes a zk_air runs it
+ * first, so a malformed program is refused instead of indexing out of bounds on the host or the GPU.  (Upstream's constraints
+ * are Rust code checked by the compiler: /root/reference/ops/src/lib.rs:52 never sees a malformed AIR.) */
+int32_t zk_air_validate(const zk_air *air, uint32_t num_challenges);
+
 /* starky::config::StarkConfig; zk_stark_config_standard_fast() == StarkConfig::standard_fast_config() */
 typedef struct {
     uint32_t security_bits;        /* 100 */

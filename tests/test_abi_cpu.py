@@ -81,3 +81,42 @@ def test_build_time_constraint_kernels_are_what_the_generator_emits(zk):
     # too small a buffer is refused, not overrun
     small = C.create_string_buffer(16)
     assert L.zk_quotient_kernel_source(prog.ref, C.c_uint32(2), C.c_uint32(1), small, C.c_size_t(16), C.byref(ln), C.byref(h)) != 0
+
+
+def test_air_validate_refuses_malformed_programs(zk):
+    """zk_air_validate (host only): a constraint program whose operands index outside its arrays is refused with
+    ZK_ERR_INVALID_ARG before it can reach the generator, the interpreter or the helper kernels."""
+    from eth_tx_proof_amd import air
+    from eth_tx_proof_amd._abi import (OP_ADD, OP_EMIT, OP_MUL, OPND_CHALLENGE, OPND_CONST, OPND_LOCAL, OPND_NEXT, OPND_PUBLIC,
+                                       OPND_REG, opnd)
+    L = zk.lib()
+    v = lambda prog, nch=2: L.zk_air_validate(prog.ref, C.c_uint32(nch))
+    assert v(air.cpu_like_air(93, 19)) == 0
+    assert v(air.cpu_like_air(1, 0)) == 0
+    assert v(air.cpu_like_air(9, 2), 0) == -1 and v(air.cpu_like_air(9, 2), 5) == -1
+    assert L.zk_air_validate(None, C.c_uint32(2)) == -1
+    C_, H = 6, 2                              # 6 trace columns, 2 helpers -> A = 2 * 3 = 6 auxiliary columns
+    ok = [(OP_MUL, 0, opnd(OPND_LOCAL, 5), opnd(OPND_NEXT, 11)), (OP_EMIT, 0, opnd(OPND_REG, 0), 0)]
+    mk = lambda ins, helpers=((0, 1, 2, 3),) * H, consts=(1,), regs=2, pubs=3: air.AirProgram(C_, pubs, list(helpers), list(consts), ins, regs)
+    assert v(mk(ok)) == 0
+    bad_programs = [
+        [(OP_MUL, 0, opnd(OPND_LOCAL, 12), opnd(OPND_LOCAL, 0))],            # LOCAL past trace + aux
+        [(OP_MUL, 0, opnd(OPND_NEXT, 12), opnd(OPND_LOCAL, 0))],             # NEXT past trace + aux
+        [(OP_ADD, 0, opnd(OPND_CONST, 1), opnd(OPND_LOCAL, 0))],             # CONST past n_constants
+        [(OP_ADD, 0, opnd(OPND_PUBLIC, 3), opnd(OPND_LOCAL, 0))],            # PUBLIC past n_public_inputs
+        [(OP_ADD, 0, opnd(OPND_CHALLENGE, 4), opnd(OPND_LOCAL, 0))],         # CHALLENGE past 2 * nch
+        [(OP_ADD, 0, opnd(OPND_REG, 2), opnd(OPND_LOCAL, 0))],               # source register past n_regs
+        [(OP_ADD, 2, opnd(OPND_LOCAL, 0), opnd(OPND_LOCAL, 0))],             # destination register past n_regs
+        [(OP_ADD, opnd(OPND_LOCAL, 0), opnd(OPND_LOCAL, 0), opnd(OPND_LOCAL, 0))],   # destination is not a register
+        [(OP_ADD, 0, opnd(6, 0), opnd(OPND_LOCAL, 0))],                      # unknown operand kind
+        [(7, 0, opnd(OPND_LOCAL, 0), 0)],                                    # unknown opcode
+        [(OP_EMIT, 0, opnd(OPND_LOCAL, 99), 0)],                             # emitted operand out of range
+    ]
+    for ins in bad_programs:
+        assert v(mk(ins)) == -1, ins
+    assert v(mk(ok, helpers=((0, 1, 2, 6),) * H)) == -1                      # helper names a column past the trace
+    # without helpers there are no auxiliary columns: LOCAL index C is already out of range
+    assert v(mk([(OP_ADD, 0, opnd(OPND_LOCAL, 6), opnd(OPND_LOCAL, 0))], helpers=())) == -1
+    # the host-only generator refuses the same programs instead of indexing out of bounds
+    ln, h = C.c_size_t(0), C.c_uint64(0)
+    assert L.zk_quotient_kernel_source(mk(bad_programs[0]).ref, C.c_uint32(2), C.c_uint32(1), None, C.c_size_t(0), C.byref(ln), C.byref(h)) == -1

@@ -250,3 +250,28 @@ def test_four_streams_full_size_units_equal_their_single_stream_proofs(zk, orc):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_north_star_target_2_23_rows_unit_proof_verifies(zk, orc):
+    """north_star's target configuration: ONE 2^23-row x 93 (+40) column unit proof on one GPU (about 45 GB resident).  Far beyond
+    what the oracle's prover can do inside a test, so parity is checked through the size-independent properties: the oracle's
+    verifier (constraints at zeta, FRI low-degree test over 2^24 points, every Merkle path) accepts the proof, rejects it after a
+    single flipped word anywhere, and a second run gives the same words (determinism of the smallest PoW witness)."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(93, 19)
+    c = zk.Context(0)
+    try:
+        d, pub = zk.synth_trace_dev(c, 93, 23, 0x5EED0023)
+        items = [(prog, 23, d, pub)]
+        proof = zk.prove_tables(c, cfg, items).copy()
+        assert proof.size == zk.proof_size_words(cfg, items)
+        assert (proof[2:] < np.uint64(P)).all()
+        assert orc.verify(cfg, [(prog, 23, None, pub)], proof) == 0
+        rng = np.random.default_rng(23)
+        for pos in rng.integers(5, proof.size, size=4):
+            bad = proof.copy(); bad[pos] ^= np.uint64(1)
+            assert orc.verify(cfg, [(prog, 23, None, pub)], bad) != 0
+        assert (zk.prove_tables(c, cfg, items) == proof).all()
+    finally:
+        c.close()

@@ -1,0 +1,75 @@
+"""BASELINE configs[4] on one GPU: a 16-unit block is sharded round-robin over ranks, every rank proves its units for real
+(HIP prover, one context per in-flight unit), the finished proofs are handed to rank 0 with sharding.gather_proofs, and rank 0
+checks every gathered proof with the oracle's verifier -- the caller shape of /root/reference/leader/src/prover.rs:26-30
+(IndexedStream.map(&TxProof) then the hand-off to fold).  Two ranks share the one GPU of the test box (gloo rendezvous: RCCL
+refuses two ranks on one device), each with four contexts, i.e. eight workers with two units each."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, threading
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+    import numpy as np, torch.distributed as dist
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import air, lib as zl, sharding
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    N_UNITS, LOG_N, COLS, HELPERS, NCTX = 16, 16, 93, 19, 4
+    cfg = E.standard_fast_config()
+    prog = air.cpu_like_air(COLS, HELPERS)
+    mine = sharding.shard_units(N_UNITS, world, rank)
+    assert len(mine) == N_UNITS // world
+    ctxs = [zl.Context(0) for _ in range(NCTX)]
+    local, pubs, errors = {}, {}, []
+    def worker(w):                                  # worker w proves units mine[w], mine[w + NCTX], ... on its own stream
+        try:
+            for u in mine[w::NCTX]:
+                d, pub = zl.synth_trace_dev(ctxs[w], COLS, LOG_N, 0x5EED0000 + 1000 * u)
+                local[u] = zl.prove_tables(ctxs[w], cfg, [(prog, LOG_N, d, pub)]).copy()
+                pubs[u] = pub
+                ctxs[w].dev_free(d)
+        except Exception as e:
+            errors.append(e)
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(NCTX)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errors, errors
+    got = sharding.gather_proofs(local, N_UNITS)
+    allpubs = [None] * world
+    dist.all_gather_object(allpubs, {u: p.tolist() for u, p in pubs.items()})
+    if rank == 0:
+        import orc
+        pub_of = {u: np.array(p, dtype=np.uint64) for d in allpubs for u, p in d.items()}
+        assert len(got) == N_UNITS and all(g is not None for g in got)
+        for u in range(N_UNITS):
+            assert orc.verify(cfg, [(prog, LOG_N, None, pub_of[u])], got[u]) == 0, u
+        assert orc.verify(cfg, [(prog, LOG_N, None, pub_of[1])], got[0]) != 0           # a proof does not verify as another unit's
+        bad = got[3].copy(); bad[len(bad) // 2] ^= np.uint64(1)
+        assert orc.verify(cfg, [(prog, LOG_N, None, pub_of[3])], bad) != 0
+        # unit u's proof is the one a single context produces for the same seed (sharding changes nothing)
+        d, pub = zl.synth_trace_dev(ctxs[0], COLS, LOG_N, 0x5EED0000 + 1000 * 9)
+        assert (zl.prove_tables(ctxs[0], cfg, [(prog, LOG_N, d, pub)]) == got[9]).all()
+        print("BLOCK_OK")
+    else:
+        assert got is None
+    for c in ctxs: c.close()
+    dist.destroy_process_group()
+""") % (ROOT, ROOT)
+
+
+def test_sixteen_unit_block_sharded_proved_gathered_verified(tmp_path):
+    script = tmp_path / "block_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29633", str(script)],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:] + out.stderr[-3000:])
+    assert "BLOCK_OK" in out.stdout
