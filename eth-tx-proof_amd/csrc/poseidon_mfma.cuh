@@ -7,9 +7,9 @@
 //   * MDS (+ next round constants): 18 matrix-core instructions per wave and layer, operands straight from the state
 //     registers (bytes XOR 0x80), results recombined from eight 25-bit limb sums per word with 13 vector instructions --
 //     against 24 multiply-adds + 5 per word on the vector ALU;
-//   * the 22 partial rounds: everything that is linear in the state is two matrix products (E = what the untouched words
-//     contribute to each s-box input, and the exit map), and only the s-box chain with its triangular feedback
-//     x_{q+1} = E[q] + sum_{j<=q} PR_D[q][j] y_j runs on the vector ALU, one permutation per lane (two v_permlane32_swap
+//   * the 22 partial rounds: the s-box chain x_{q+1} = E[q] + sum_{j<=q} PR_D[q][j] y_j runs one permutation per lane in blocks
+//     of four rounds; what a block needs from the state (E) and from all earlier blocks is one matrix product per block, the exit
+//     map another, and only the in-block feedback (31 products per permutation) runs on the vector ALU (two v_permlane32_swap
 //     exchanges per word in and out).
 // The rare-repair protocol of psd::core<false> (sticky word, exact redo) carries over unchanged: the matrix products and the
 // recombination are exact.
@@ -120,62 +120,66 @@ template <bool EXACT> struct perm {
         }
     }
 
+    // The 22 partial rounds.  Chain:  y_q = x_q^7 + K[q];  x_{q+1} = E[q] + 25 y_q + sum_{j<q} PR_D[q][j] y_j  (x_0 = state word 0).
+    // Rounds run in blocks of four.  For the rows of block b everything that is known when the block starts -- E (linear in the
+    // state) and the feedback of all earlier blocks -- is ONE matrix product F = A_F[b] * (state | y_0 .. y_{4b-1}) whose K grows by
+    // one k-step per finished block; the vector ALU only adds the in-block feedback (0 + 1 + 2 + 3 products per block instead of
+    // q products in round q: 31 instead of 210 per permutation).  The chain itself runs one permutation per lane (lane (n, h) runs
+    // permutation (c = h, n)); matrix-core operands and results are in pair layout, two v_permlane32_swap exchanges per word.
     __device__ __forceinline__ void partial_rounds(u64 (&s)[2][6]) {
-        // ---- E = G1 * s for both column tiles, in pair layout: E[c][o] = E_(c,n)[11h + o]
-        u64 E[2][12];
-        {
-            psdm_v4i b[2][3];
-#pragma unroll
-            for (int c = 0; c < 2; c++)
-#pragma unroll
-                for (int k = 0; k < 3; k++) b[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
-#pragma unroll
-            for (int t = 0; t < 6; t++) {
-                const psdm_v16i cin = ld16(&T->Cin_E[t][lane >> 5][0]);
-                const psdm_v4i a0 = ld4(&T->A_E[t][0][lane][0]), a1 = ld4(&T->A_E[t][1][lane][0]), a2 = ld4(&T->A_E[t][2][lane][0]);
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    psdm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[c][0], cin, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[c][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b[c][2], acc, 0, 0, 0);
-                    recombine2(K, acc, E[c][2 * t], E[c][2 * t + 1]);
-                }
-            }
-        }
-        // ---- to one permutation per lane: lane (n, h) runs permutation (c = h, n)
-        u64 Eo[22];
-#pragma unroll
-        for (int o = 0; o < 11; o++) { u64 y = E[0][o], x = E[1][o]; swap32(y, x); Eo[o] = y; Eo[11 + o] = x; }
-        u64 x;
-        { u64 d = s[0][0], w = s[1][0]; swap32(d, w); x = d; }
-        // ---- s-box chain: y_q = x_q^7 + K[q];  x_{q+1} = E[q] + 25 y_q + sum_{j<q} PR_D[q][j] y_j   (x_22 comes out of G2)
-        u64 y[24];
-        // (the 210 wave-uniform constants PSD_PR_D are scalar loads that hipcc hoists out of the caller's loop and parks in
-        // VGPR lanes, one v_readlane per use; measured faster than LDS broadcast reads or loads kept inside the serial chain)
-        const u64 *Dm = PSD_PR_D, *Kc = PSD_PR_K;
-#pragma unroll
-        for (int q = 0; q < 22; q++) {
-            y[q] = psd::wadd_c(pc.sbox(x), Kc[q]);
-            if (q == 21) break;
-            psd::acc3 a; a.init();
-            a.c0 = (u64)(u32)Eo[q] + (u64)(u32)y[q] * (u32)PSD_M00;
-            a.c1 = (Eo[q] >> 32) + (y[q] >> 32) * (u32)PSD_M00;
-#pragma unroll
-            for (int j = 0; j < q; j++) a.mac_s(Dm[22 * q + j], y[j]);
-            x = pc.reduce(a);
-        }
-        y[22] = 0; y[23] = 0;
-        // ---- back to pair layout: Y[0][sl] = y_(0,n)[11h + sl], Y[1][sl] = y_(1,n)[11h + sl]
-        u64 Y[2][12];
-#pragma unroll
-        for (int sl = 0; sl < 11; sl++) { u64 lo = y[sl], hi = y[11 + sl]; swap32(lo, hi); Y[0][sl] = lo; Y[1][sl] = hi; }
-        Y[0][11] = 0; Y[1][11] = 0;
-        // ---- exit map G2 (K = 12 state words + 2 x 12 slots of y), + RC[26]
-        psdm_v4i bs[2][3];                 // the state enters through its operand bytes only: s can take the results
+        psdm_v4i bs[2][3];                 // operand bytes of the state; the state registers themselves are free from here on
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int k = 0; k < 3; k++) bs[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
+        psdm_v4i by[2][6];                 // operand bytes of the finished blocks' s-box outputs
+        u64 x;
+        { u64 d = s[0][0], w = s[1][0]; swap32(d, w); x = d; }
+        const u64 *Dm = PSD_PR_D, *Kc = PSD_PR_K;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            // ---- F rows 4b .. 4b+3 for both column tiles, then to one permutation per lane
+            u64 F[4];
+            {
+                const psdm_v16i cin = ld16(&T->Cin_F[b][lane >> 5][0]);
+                psdm_v16i acc0 = cin, acc1 = cin;
+#pragma unroll
+                for (int k = 0; k < 3 + b; k++) {
+                    const psdm_v4i a = ld4(&T->A_F[b][k][lane][0]);
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[1][k] : by[1][k - 3], acc1, 0, 0, 0);
+                }
+                u64 f0[2], f1[2];
+                recombine2(K, acc0, f0[0], f0[1]);
+                recombine2(K, acc1, f1[0], f1[1]);
+#pragma unroll
+                for (int i = 0; i < 2; i++) { u64 yy = f0[i], xx = f1[i]; swap32(yy, xx); F[i] = yy; F[2 + i] = xx; }
+            }
+            // ---- four rounds of the chain (two in the last block)
+            u64 y[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int q = 4 * b + i;
+                if (q > 21) { y[i] = 0; continue; }
+                y[i] = psd::wadd_c(pc.sbox(x), Kc[q]);
+                if (q == 21) continue;
+                // F[q] + 25 y_q: two 38-bit column sums, folded like an MDS row; then one multiply-add per in-block term
+                u64 al = (u64)(u32)F[i] + (u64)(u32)y[i] * (u32)PSD_M00, ah = (F[i] >> 32) + (y[i] >> 32) * (u32)PSD_M00;
+                u32 th, cy;
+                th = __builtin_addc((u32)(al >> 32), (u32)ah, 0u, &cy);
+                u32 high = (u32)(ah >> 32) + cy;
+                x = gl_mad_eps(high, ((u64)th << 32) | (u32)al);
+#pragma unroll
+                for (int j = 0; j < i; j++) x = pc.mul_add(Dm[22 * q + 4 * b + j], y[j], x);
+            }
+            // ---- the block's s-box outputs to pair layout, as operand bytes
+            {
+                u64 v0 = y[0], s0 = y[2], v1 = y[1], s1 = y[3];
+                swap32(v0, s0); swap32(v1, s1);
+                by[0][b] = bfrag(v0, v1); by[1][b] = bfrag(s0, s1);
+            }
+        }
+        // ---- exit map G2 (K = 12 state words + 6 blocks of y), + RC[26]
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const psdm_v16i cin = ld16(&T->Cin_G2[t][lane >> 5][0]);
@@ -183,10 +187,8 @@ template <bool EXACT> struct perm {
 #pragma unroll
             for (int k = 0; k < 9; k++) {
                 const psdm_v4i a = ld4(&T->A_G2[t][k][lane][0]);
-                const psdm_v4i b0 = k < 3 ? bs[0][k] : bfrag(Y[0][2 * (k - 3)], Y[0][2 * (k - 3) + 1]);
-                const psdm_v4i b1 = k < 3 ? bs[1][k] : bfrag(Y[1][2 * (k - 3)], Y[1][2 * (k - 3) + 1]);
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[1][k] : by[1][k - 3], acc1, 0, 0, 0);
             }
             recombine2(K, acc0, s[0][2 * t], s[0][2 * t + 1]);
             recombine2(K, acc1, s[1][2 * t], s[1][2 * t + 1]);

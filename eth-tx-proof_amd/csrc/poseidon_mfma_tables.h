@@ -29,9 +29,14 @@
 struct PsdmTables {
     int8_t A_mds[3][3][64][16];
     int32_t Cin_mds[8][3][2][16];      // [layer][tile][lane half][register]; layer L: next-layer constants RC[L+1] (L<3), PR_FIRST (3), RC[27+L-4] (4..6), none (7)
-    int8_t A_E[6][3][64][16];          // E[e] = <vhat_e, PR_INIT * s[1..]>, e = 11h' + slot
-    int32_t Cin_E[6][2][16];
-    int8_t A_G2[3][9][64][16];         // exit of the partial rounds: K = 12 state words + 22 (24 slots) s-box outputs
+    // s-box chain of the partial rounds in blocks of four rounds: tile b gives, for rows q = 4b .. 4b+3 (lane half h', slot i:
+    // q = 4b + 2h' + i), F[q] = E[q] + sum_{j < 4b} PR_D[q][j] y_j with E[q] = <vhat_q, PR_INIT * s[1..]>.
+    // K-steps: 0..2 = the 12 state words, 3 + b' = the four s-box outputs y_{4b'} .. y_{4b'+3} of block b' < b (lane half h, word
+    // w: y_{4b' + 2h + w}) -- everything already known when block b starts is a matrix product; only the in-block feedback
+    // (six products per block) stays on the vector ALU.
+    int8_t A_F[6][8][64][16];
+    int32_t Cin_F[6][2][16];
+    int8_t A_G2[3][9][64][16];         // exit of the partial rounds: K = 12 state words + 22 (24 slots, blocks of four) s-box outputs
     int32_t Cin_G2[3][2][16];          // + RC[26]
     uint64_t RC_first[12];
 };
@@ -138,16 +143,18 @@ static void build(PsdmTables &t) {
             G1[e][1 + j] = acc;
         }
     }
-    fill(6, 3, &t.A_E[0][0][0][0], &t.Cin_E[0][0][0], [](int hp, int slot) { return slot < 11 ? 11 * hp + slot : -1; }, state_kword,
-         [&](int e, int wi) { return G1[e][wi]; }, [](int) { return (u64)0; });
-    // ---- G2: new s[0] = E[21] + sum_q PR_D[21][q] y_q;  new s[1+i] = (PR_INIT s[1..])[i] + sum_q PR_W[q][i] y_q;  + RC[26]
-    // K words: 0..11 = state at the entry of the partial rounds, 12 + q = y_q
-    auto g2_kword = [](int ks, int h, int wsel) {
+    // K words: 0..11 = state at the entry of the partial rounds, 12 + q = y_q (k-step 3 + b', lane half h, word w: q = 4b' + 2h + w)
+    auto chain_kword = [](int ks, int h, int wsel) {
         if (ks < 3) return 6 * h + 2 * ks + wsel;
-        int sl = 2 * (ks - 3) + wsel;
-        return sl < 11 ? 12 + 11 * h + sl : -1;
+        int q = 4 * (ks - 3) + 2 * h + wsel;
+        return q < 22 ? 12 + q : -1;
     };
-    fill(3, 9, &t.A_G2[0][0][0][0], &t.Cin_G2[0][0][0], word_out, g2_kword,
+    for (int b = 0; b < 6; b++)
+        fill(1, 3 + b, &t.A_F[b][0][0][0], &t.Cin_F[b][0][0],
+             [b](int hp, int slot) { int q = 4 * b + 2 * hp + slot; return (slot < 2 && q < 21) ? q : -1; }, chain_kword,
+             [&](int q, int kw) -> u64 { return kw < 12 ? G1[q][kw] : PSD_PR_D[22 * q + (kw - 12)]; }, [](int) { return (u64)0; });
+    // ---- G2: new s[0] = E[21] + sum_q PR_D[21][q] y_q;  new s[1+i] = (PR_INIT s[1..])[i] + sum_q PR_W[q][i] y_q;  + RC[26]
+    fill(3, 9, &t.A_G2[0][0][0][0], &t.Cin_G2[0][0][0], word_out, chain_kword,
          [&](int W, int kw) -> u64 {
              if (kw < 12) {
                  if (W == 0) return G1[21][kw];

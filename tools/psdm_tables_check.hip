@@ -1,7 +1,7 @@
 // Host-only check of the matrix-core Poseidon tables (poseidon_mfma_tables.h): emulates v_mfma_i32_32x32x32_i8 with plain integer
 // loops (operand and result lane maps as documented there) and verifies, for random states, that
 //   * the MDS tables reproduce  MDS * s + next-layer constants,
-//   * E / G2 reproduce the partial rounds' entry values and exit map
+//   * F (per block of four rounds: E + the feedback of earlier blocks) and G2 reproduce the partial rounds' chain inputs and exit map
 // against direct modular arithmetic on the constants of poseidon_constants.inc.  No GPU needed.
 // build: hipcc -O2 -std=c++17 tools/psdm_tables_check.hip -o tools/bin/psdm_tables_check   (host code only)
 #include <stdio.h>
@@ -78,16 +78,24 @@ int main() {
             if (d != d2) { if (bad++ < 5) printf("PR_D row %d mismatch\n", q); }
             x = d;
         }
-        {
+        // k-step 3 + b' carries y_{4b'} .. y_{4b'+3}: lane half h, word w -> y_{4b' + 2h + w}
+        for (int ks = 3; ks < 9; ks++) for (int h = 0; h < 2; h++) for (int w = 0; w < 2; w++) {
+            int q = 4 * (ks - 3) + 2 * h + w;
+            kw[ks][h][w] = q < 22 ? y[q] : splitmix(z);         // the two padding slots of the last block may hold anything
+        }
+        for (int b = 0; b < 6; b++) {
+            // F[q] = E[q] + sum_{j < 4b} PR_D[q][j] y_j for the rows q = 4b + 2h' + slot of block b
             u64 out[2][12];
-            emulate(6, 3, &t.A_E[0][0][0][0], &t.Cin_E[0][0][0], kw, out);
-            for (int q = 0; q < 22; q++) if (gl_canon(out[q / 11][q % 11]) != E_want[q]) { if (bad++ < 5) printf("E[%d] mismatch\n", q); }
+            emulate(1, 3 + b, &t.A_F[b][0][0][0], &t.Cin_F[b][0][0], kw, out);
+            for (int hp = 0; hp < 2; hp++) for (int sl = 0; sl < 2; sl++) {
+                int q = 4 * b + 2 * hp + sl;
+                if (q > 20) continue;
+                u64 want = E_want[q];
+                for (int j = 0; j < 4 * b; j++) want = gl_add(want, gl_mul(PSD_PR_D[22 * q + j], y[j]));
+                if (gl_canon(out[hp][sl]) != want) { if (bad++ < 5) printf("F[%d] mismatch\n", q); }
+            }
         }
         {
-            for (int ks = 3; ks < 9; ks++) for (int h = 0; h < 2; h++) for (int w = 0; w < 2; w++) {
-                int sl = 2 * (ks - 3) + w;
-                kw[ks][h][w] = sl < 11 ? y[11 * h + sl] + (trial & 1 ? 0 : 0) : 0;
-            }
             u64 out[2][12];
             emulate(3, 9, &t.A_G2[0][0][0][0], &t.Cin_G2[0][0][0], kw, out);
             for (int W = 0; W < 12; W++) {
