@@ -172,6 +172,93 @@ template <bool EXACT> struct glx {
             : [fl] "+s"(fl) : [d] "v"(d), [p] "s"((u64)GL_P) : "vcc");
         return d;
     }
+    // ---- weak butterflies for the NTT networks.  Operands and results are ANY representative in [0, 2^64) of their residue:
+    // u + v wraps with carry c -> + c*eps (2^64 = eps); u - v wraps with borrow b -> - b*eps.  Each repair can wrap a second time only
+    // for operands within 2^32 of the ends of the range (about one lane in 2^32): that second carry / borrow goes into the sticky
+    // word and the kernel redoes the tile exactly.  Two butterflies per call: their four carry chains are interleaved so that every
+    // scalar carry mask is read at least three instructions after it is written (gfx950 needs two wait states between a vector write
+    // of an SGPR and a vector read of it; inline asm is not padded by the compiler).  9 instructions per butterfly instead of 14.
+    // The EXACT variant is the canonical gl_add / gl_sub pair.
+    __device__ __forceinline__ void bfly2(u64 &u1, u64 &v1, u64 &u2, u64 &v2) {
+        if (EXACT) {
+            u64 a1 = gl_add(u1, v1), d1 = gl_sub(u1, v1), a2 = gl_add(u2, v2), d2 = gl_sub(u2, v2);
+            u1 = a1; v1 = d1; u2 = a2; v2 = d2;
+            return;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        u32 u1l = (u32)u1, u1h = (u32)(u1 >> 32), v1l = (u32)v1, v1h = (u32)(v1 >> 32);
+        u32 u2l = (u32)u2, u2h = (u32)(u2 >> 32), v2l = (u32)v2, v2h = (u32)(v2 >> 32);
+        u32 a1l, a1h, d1l, d1h, a2l, a2h, d2l, d2h, m0, m1, m2, m3;
+        u64 k0, k1, k2, k3;
+        asm("v_add_co_u32 %[a1l], %[k0], %[u1l], %[v1l]\n\t"
+            "v_sub_co_u32 %[d1l], %[k1], %[u1l], %[v1l]\n\t"
+            "v_add_co_u32 %[a2l], %[k2], %[u2l], %[v2l]\n\t"
+            "v_sub_co_u32 %[d2l], %[k3], %[u2l], %[v2l]\n\t"
+            "v_addc_co_u32 %[a1h], %[k0], %[u1h], %[v1h], %[k0]\n\t"
+            "v_subb_co_u32 %[d1h], %[k1], %[u1h], %[v1h], %[k1]\n\t"
+            "v_addc_co_u32 %[a2h], %[k2], %[u2h], %[v2h], %[k2]\n\t"
+            "v_subb_co_u32 %[d2h], %[k3], %[u2h], %[v2h], %[k3]\n\t"
+            "v_cndmask_b32_e64 %[m0], 0, -1, %[k0]\n\t"
+            "v_cndmask_b32_e64 %[m1], 0, -1, %[k1]\n\t"
+            "v_cndmask_b32_e64 %[m2], 0, -1, %[k2]\n\t"
+            "v_cndmask_b32_e64 %[m3], 0, -1, %[k3]\n\t"
+            : [a1l] "=&v"(a1l), [a1h] "=&v"(a1h), [d1l] "=&v"(d1l), [d1h] "=&v"(d1h), [a2l] "=&v"(a2l), [a2h] "=&v"(a2h),
+              [d2l] "=&v"(d2l), [d2h] "=&v"(d2h), [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3),
+              [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
+            : [u1l] "v"(u1l), [u1h] "v"(u1h), [v1l] "v"(v1l), [v1h] "v"(v1h), [u2l] "v"(u2l), [u2h] "v"(u2h), [v2l] "v"(v2l), [v2h] "v"(v2h));
+        u64 a1 = ((u64)a1h << 32) | a1l, a2 = ((u64)a2h << 32) | a2l;
+        asm("v_mad_u64_u32 %[a1], %[k0], %[m0], 1, %[a1]\n\t"
+            "v_sub_co_u32 %[d1l], %[k1], %[d1l], %[m1]\n\t"
+            "v_mad_u64_u32 %[a2], %[k2], %[m2], 1, %[a2]\n\t"
+            "v_sub_co_u32 %[d2l], %[k3], %[d2l], %[m3]\n\t"
+            "s_or_b64 %[fl], %[fl], %[k0]\n\t"
+            "v_subbrev_co_u32 %[d1h], %[k1], 0, %[d1h], %[k1]\n\t"
+            "s_or_b64 %[fl], %[fl], %[k2]\n\t"
+            "v_subbrev_co_u32 %[d2h], %[k3], 0, %[d2h], %[k3]\n\t"
+            "s_or_b64 %[fl], %[fl], %[k1]\n\t"
+            "s_or_b64 %[fl], %[fl], %[k3]\n\t"
+            : [a1] "+v"(a1), [a2] "+v"(a2), [d1l] "+v"(d1l), [d1h] "+v"(d1h), [d2l] "+v"(d2l), [d2h] "+v"(d2h), [fl] "+s"(fl),
+              [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
+            : [m0] "v"(m0), [m1] "v"(m1), [m2] "v"(m2), [m3] "v"(m3));
+        u1 = a1; v1 = ((u64)d1h << 32) | d1l; u2 = a2; v2 = ((u64)d2h << 32) | d2l;
+#endif
+    }
+    // one butterfly (radix-2 tails): the same arithmetic with explicit pads where no other chain fills the wait states
+    __device__ __forceinline__ void bfly1(u64 &u, u64 &v) {
+        if (EXACT) { u64 a = gl_add(u, v), d = gl_sub(u, v); u = a; v = d; return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        u32 ul = (u32)u, uh = (u32)(u >> 32), vl = (u32)v, vh = (u32)(v >> 32), al, ah, dl, dh, m0, m1;
+        u64 k0, k1;
+        asm("v_add_co_u32 %[al], %[k0], %[ul], %[vl]\n\t"
+            "v_sub_co_u32 %[dl], %[k1], %[ul], %[vl]\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %[ah], %[k0], %[uh], %[vh], %[k0]\n\t"
+            "v_subb_co_u32 %[dh], %[k1], %[uh], %[vh], %[k1]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[m0], 0, -1, %[k0]\n\t"
+            "v_cndmask_b32_e64 %[m1], 0, -1, %[k1]\n\t"
+            : [al] "=&v"(al), [ah] "=&v"(ah), [dl] "=&v"(dl), [dh] "=&v"(dh), [m0] "=&v"(m0), [m1] "=&v"(m1), [k0] "=&s"(k0), [k1] "=&s"(k1)
+            : [ul] "v"(ul), [uh] "v"(uh), [vl] "v"(vl), [vh] "v"(vh));
+        u64 a = ((u64)ah << 32) | al;
+        asm("v_sub_co_u32 %[dl], %[k1], %[dl], %[m1]\n\t"
+            "v_mad_u64_u32 %[a], %[k0], %[m0], 1, %[a]\n\t"
+            "s_or_b64 %[fl], %[fl], %[k0]\n\t"
+            "v_subbrev_co_u32 %[dh], %[k1], 0, %[dh], %[k1]\n\t"
+            "s_or_b64 %[fl], %[fl], %[k1]\n\t"
+            : [a] "+v"(a), [dl] "+v"(dl), [dh] "+v"(dh), [fl] "+s"(fl), [k0] "=&s"(k0), [k1] "=&s"(k1)
+            : [m0] "v"(m0), [m1] "v"(m1));
+        u = a; v = ((u64)dh << 32) | dl;
+#endif
+    }
+    // flags a weak value that is not canonical (about one in 2^32): results headed for memory must be canonical
+    __device__ __forceinline__ void check_canon(u64 x) {
+        if (EXACT) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("v_cmp_ge_u64 vcc, %[x], %[p]\n\t"
+            "s_or_b64 %[fl], %[fl], vcc\n\t"
+            : [fl] "+s"(fl) : [x] "v"(x), [p] "s"((u64)GL_P) : "vcc");
+#endif
+    }
     // a*b + c (c canonical): c's words join the first two columns ((2^32-1)^2 + 2(2^32-1) = 2^64-1: no overflow)
     __device__ __forceinline__ u64 mul_add(u64 a, u64 b, u64 c) {
         if (EXACT) return gl_mul_add(a, b, c);

@@ -25,20 +25,29 @@ __device__ __forceinline__ void radix_net(G &g, u64 (&x)[16], const int g0, cons
 #pragma unroll
     for (int s = 0; s < Q; s++) {
         const int h = DIT ? s : (Q - 1 - s);
+        // the 2^(Q-1) butterflies of the layer, two per step (their carry chains interleave inside G::bfly2)
 #pragma unroll
-        for (int i = 0; i < (1 << Q); i++) {
-            if (i & (1 << h)) continue;
-            const int j = i + (1 << h);
-            const int e = (i & ((1 << h) - 1)) << (Q - 1 - h);      // exponent of w_{2^Q}
-            const int e16 = e << (4 - Q);                           // as a power of w_16
-            u64 u = x[g0 + i], v = x[g0 + j];
+        for (int b0 = 0; b0 < (1 << (Q - 1)); b0 += 2) {
+            const int i1 = ((b0 >> h) << (h + 1)) | (b0 & ((1 << h) - 1)), j1 = i1 + (1 << h);
+            const int e1 = ((i1 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);            // twiddle as a power of w_16
+            if (Q == 1) {
+                // (a single butterfly per layer only in the radix-2 tail phase)
+                if (DIT && e1) x[g0 + j1] = g.mul(x[g0 + j1], tw16[e1]);
+                g.bfly1(x[g0 + i1], x[g0 + j1]);
+                if (!DIT && e1) x[g0 + j1] = g.mul(x[g0 + j1], tw16[e1]);
+                continue;
+            }
+            const int b1 = b0 + 1;
+            const int i2 = ((b1 >> h) << (h + 1)) | (b1 & ((1 << h) - 1)), j2 = i2 + (1 << h);
+            const int e2 = ((i2 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);
             if (DIT) {
-                if (e16) v = g.mul(v, tw16[e16]);
-                x[g0 + i] = gl_add(u, v); x[g0 + j] = gl_sub(u, v);
-            } else {
-                x[g0 + i] = gl_add(u, v);
-                u64 d = gl_sub(u, v);
-                x[g0 + j] = e16 ? g.mul(d, tw16[e16]) : d;
+                if (e1) x[g0 + j1] = g.mul(x[g0 + j1], tw16[e1]);
+                if (e2) x[g0 + j2] = g.mul(x[g0 + j2], tw16[e2]);
+            }
+            g.bfly2(x[g0 + i1], x[g0 + j1], x[g0 + i2], x[g0 + j2]);
+            if (!DIT) {
+                if (e1) x[g0 + j1] = g.mul(x[g0 + j1], tw16[e1]);
+                if (e2) x[g0 + j2] = g.mul(x[g0 + j2], tw16[e2]);
             }
         }
     }
@@ -239,13 +248,20 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
         }
         if (wact) radix_net<4, true>(fx, x, 0, tw16);
     }
+    // the networks work on weak residues: anything that leaves this function must be canonical (or flag the tile for the exact redo)
+    if (wact) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) fx.check_canon(x[q]);
+    }
 
     };
     {
         glx<false> gf; gf.fl = 0;
         compute(gf);
         // a skipped rare repair anywhere in the workgroup (waves exchange through LDS): redo the tile with every repair in place
+#ifndef ZK_ISA_COUNT_FAST_ONLY      // analysis builds (tools/isa_mix.py) drop the exact twin so that the static mix is the fast path's
         if (__syncthreads_or((gf.fl != 0) | p.force_redo)) { glx<true> ge; ge.fl = 0; compute(ge); }
+#endif
     }
 
     // ---------------------------------------------------------------- store
@@ -337,7 +353,9 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     {
         glx<false> gf; gf.fl = 0;
         store_plain(gf);
+#ifndef ZK_ISA_COUNT_FAST_ONLY
         if ((gf.fl != 0) | p.force_redo) { glx<true> ge; ge.fl = 0; store_plain(ge); }
+#endif
     }
 }
 
