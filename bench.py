@@ -279,7 +279,7 @@ def main():
     pcie = None
     if not args.no_pcie and world == 1 and hasattr(zl, "pinned_empty"):
         for s in range(args.inflight):
-            h = zl.pinned_empty((C, n))
+            h = zl.pinned_empty(ctxs[s], (C, n))
             h[...] = ctxs[s].download(traces[s].data_ptr(), (C, n))
             host_traces[s] = h
         step(); fence()

@@ -81,6 +81,36 @@ int32_t zk_ctx::upload_small(void *d_dst, const void *src, size_t bytes) {
     return ZK_OK;
 }
 
+#define ZK_CHUNK_BYTES ((size_t)32 << 20)
+int32_t zk_ctx::upload_large(void *d_dst, const void *src, size_t bytes, hipStream_t on) {
+    if (!bytes) return ZK_OK;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged)) {
+        // pinned (or device) source: one asynchronous copy, the caller keeps the buffer alive until the work has been waited for
+        if (hipMemcpyAsync(d_dst, src, bytes, hipMemcpyDefault, on) != hipSuccess) return fail(ZK_ERR_HIP, "upload_large: hipMemcpyAsync");
+        return ZK_OK;
+    }
+    (void)hipGetLastError();                                   // an unregistered pointer is reported as an error: pageable memory
+    for (int i = 0; i < 2; i++) {
+        if (!h_chunk[i] && hipHostMalloc((void **)&h_chunk[i], ZK_CHUNK_BYTES, hipHostMallocDefault) != hipSuccess) { h_chunk[i] = nullptr; return fail(ZK_ERR_OOM, "upload_large: pinned chunk"); }
+        if (!chunk_free[i] && hipEventCreateWithFlags(&chunk_free[i], hipEventDisableTiming) != hipSuccess) return fail(ZK_ERR_HIP, "upload_large: event");
+    }
+    size_t off = 0; int i = 0;
+    while (off < bytes) {
+        const size_t len = bytes - off < ZK_CHUNK_BYTES ? bytes - off : ZK_CHUNK_BYTES;
+        if (hipEventSynchronize(chunk_free[i]) != hipSuccess) return fail(ZK_ERR_HIP, "upload_large: event wait");   // never recorded: returns at once
+        memcpy(h_chunk[i], (const char *)src + off, len);
+        if (hipMemcpyAsync((char *)d_dst + off, h_chunk[i], len, hipMemcpyHostToDevice, on) != hipSuccess || hipEventRecord(chunk_free[i], on) != hipSuccess)
+            return fail(ZK_ERR_HIP, "upload_large: chunk copy");
+        off += len; i ^= 1;
+    }
+    return ZK_OK;
+}
+void zk_ctx::wait_pending_uploads() {
+    for (hipEvent_t e : pending_uploads) { hipStreamWaitEvent(stream, e, 0); event_pool.push_back(e); }
+    pending_uploads.clear();
+}
+
 void zk_ctx::release(void *p) {
     if (!p) return;
     auto it = block_size.find(p);
@@ -162,6 +192,9 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     hipFree(c->d_err);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_out) hipHostFree(c->h_out);
+    if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+    for (hipEvent_t e : c->pending_uploads) hipEventDestroy(e);
+    for (int i = 0; i < 2; i++) { if (c->h_chunk[i]) hipHostFree(c->h_chunk[i]); if (c->chunk_free[i]) hipEventDestroy(c->chunk_free[i]); }
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return ZK_OK;
@@ -207,6 +240,39 @@ int32_t zk_dev_alloc(zk_ctx *c, size_t bytes, void **d_ptr) {
 int32_t zk_dev_free(zk_ctx *c, void *d_ptr) {
     if (!c) return ZK_ERR_INVALID_ARG;
     c->release(d_ptr);
+    return ZK_OK;
+}
+int32_t zk_host_alloc(zk_ctx *c, size_t bytes, void **h_ptr) {
+    if (!c || !h_ptr) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    *h_ptr = nullptr;
+    if (hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *h_ptr = nullptr; return c->fail(ZK_ERR_OOM, "zk_host_alloc: hipHostMalloc"); }
+    return ZK_OK;
+}
+int32_t zk_host_free(zk_ctx *c, void *h_ptr) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    if (h_ptr && hipHostFree(h_ptr) != hipSuccess) return c->fail(ZK_ERR_HIP, "zk_host_free");
+    return ZK_OK;
+}
+int32_t zk_trace_upload_async(zk_ctx *c, const uint64_t *trace, size_t n_words, uint64_t **d_ptr) {
+    if (!c || !trace || !d_ptr || !n_words) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    *d_ptr = nullptr;
+    if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { c->copy_stream = nullptr; return c->fail(ZK_ERR_HIP, "upload_async: copy stream"); }
+    void *d = c->alloc(n_words * sizeof(uint64_t));
+    if (!d) return c->fail(ZK_ERR_OOM, "upload_async: device memory");
+    auto get_event = [&]() { if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; } hipEvent_t e = nullptr; hipEventCreate(&e); return e; };
+    // the block may have been released by work that is still enqueued on the main stream: the copy starts behind everything enqueued
+    // there SO FAR (and therefore overlaps whatever the caller enqueues next, e.g. the current unit's proof)
+    hipEvent_t before = get_event(), done = get_event();
+    int32_t rc = ZK_OK;
+    if (!before || !done || hipEventRecord(before, c->stream) != hipSuccess || hipStreamWaitEvent(c->copy_stream, before, 0) != hipSuccess) rc = c->fail(ZK_ERR_HIP, "upload_async: ordering");
+    if (rc == ZK_OK) rc = c->upload_large(d, trace, n_words * sizeof(uint64_t), c->copy_stream);
+    if (rc == ZK_OK && hipEventRecord(done, c->copy_stream) != hipSuccess) rc = c->fail(ZK_ERR_HIP, "upload_async: event");
+    if (before) c->event_pool.push_back(before);
+    if (rc != ZK_OK) { if (done) c->event_pool.push_back(done); hipStreamSynchronize(c->copy_stream); c->release(d); return rc; }
+    c->pending_uploads.push_back(done);
+    *d_ptr = (uint64_t *)d;
     return ZK_OK;
 }
 int32_t zk_dev_upload(zk_ctx *c, void *d_dst, const void *src, size_t bytes) {

@@ -15,6 +15,7 @@
 #include <map>
 #include <tuple>
 #include <stdlib.h>
+#include <type_traits>
 
 template <int Q> struct BR { __device__ static constexpr u32 rev(u32 i) { u32 r = 0; for (int b = 0; b < Q; b++) if (i & (1u << b)) r |= 1u << (Q - 1 - b); return r; } };
 
@@ -114,13 +115,15 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     };
     // mapping ids: 0 = H, 1 = M, 2 = L
     auto map_any = [&](int m, int q, u32 &t, u32 &slot) { if (m == 0) map_H(q, t, slot); else if (m == 1) map_M(q, t, slot); else map_L(q, t, slot); };
-    // global position of (t, slot); returns false when the row is past the end (ROW tail block)
-    auto gpos = [&](u32 t, u32 slot, size_t &c, size_t &pos) -> bool {
+    // global position of (t, slot); returns false when the row is past the end (ROW tail block).  Positions and row numbers fit
+    // 32 bits (k <= 30 and the launcher bounds rows * columns), so only the final address is formed in 64 bits.
+    const u32 base32 = (u32)base, row032 = (u32)row0, rpc_mask = (u32)rows_per_col - 1u, kW = (u32)(p.k - W), total32 = (u32)total_rows;
+    auto gpos = [&](u32 t, u32 slot, size_t &c, u32 &pos) -> bool {
         if (ROW) {
-            size_t rid = row0 + t;
-            if (rid >= total_rows) return false;
-            c = rid / rows_per_col; pos = ((rid % rows_per_col) << W) + slot;
-        } else { c = col; pos = base + ((size_t)slot << S) + t; }
+            u32 rid = row032 + t;
+            if (rid >= total32) return false;
+            c = rid >> kW; pos = ((rid & rpc_mask) << W) + slot;      // rows_per_col = 2^(k-W)
+        } else { c = col; pos = base32 + (slot << S) + t; }
         return true;
     };
 
@@ -147,25 +150,28 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     // Loads (and the factor loads) are guarded per lane and issued back to back; the products run after them in wave-uniform
     // control flow, because the sticky word of glx<false> is a scalar: inactive lanes multiply 0 by 1.
     {
+        // which factor an element gets is a property of the PASS: decided once here, so that the unrolled per-element code below
+        // carries no run-time branch (mode 0: none, 1: one coalesced table read, 2: the two-level tables)
         const bool need_mul = p.load_tab || p.preA || (DIT && S > 0);
         u64 f[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) { x[q] = 0; f[q] = 1; }
-        if (act) {
+        auto load_all = [&](auto MODE, auto CANON) {
+            if (!act) return;
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 u32 t, slot; map_any(load_map, q, t, slot);
-                size_t c, pos;
+                size_t c; u32 pos;
                 if (gpos(t, slot, c, pos)) {
                     u64 v = p.in[c * p.in_stride + pos];
-                    if (p.canon_in) v = gl_canon(v);
+                    if (decltype(CANON)::value) v = gl_canon(v);
                     x[q] = v;
-                    if (p.load_tab) f[q] = p.load_tab[pos];
-                    else {
+                    if (decltype(MODE)::value == 1) f[q] = p.load_tab[pos];
+                    else if (decltype(MODE)::value == 2) {
                         u64 g1 = 1;
-                        if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32((u32)pos, p.k) : (u32)pos; g1 = tab2(p.preA, p.preB, j); }
+                        if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32(pos, p.k) : pos; g1 = tab2(p.preA, p.preB, j); }
                         if (DIT && S > 0) {
-                            u32 inner = (u32)(pos & (((size_t)1 << S) - 1));
+                            u32 inner = pos & ((1u << S) - 1);
                             u64 g2 = tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner);
                             g1 = p.preA ? gl_mul(g1, g2) : g2;
                         }
@@ -173,6 +179,12 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                     }
                 }
             }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        if (p.canon_in) {
+            if (p.load_tab) load_all(I1{}, std::true_type{}); else if (need_mul) load_all(I2{}, std::true_type{}); else load_all(I0{}, std::true_type{});
+        } else {
+            if (p.load_tab) load_all(I1{}, std::false_type{}); else if (need_mul) load_all(I2{}, std::false_type{}); else load_all(I0{}, std::false_type{});
         }
         if (wact && need_mul) {
 #pragma unroll
@@ -286,27 +298,31 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             }
         } else to_lds(0);
         __syncthreads();
-        if (act) {
+        auto scatter = [&](auto POST) {
+            if (!act) return;
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 u32 lin = tid + nact * q;
                 u32 t = lin >> W, pe = lin & ((1u << W) - 1), e = bitrev_u32(pe, W);
                 u64 v = pswz ? sh[pidx(t, pe)] : sh[lds_idx(t, e)];
-                size_t c, pos; u32 K;
+                size_t c; u32 pos, K;
                 if (ROW) {
-                    size_t rid = row0 + t;
-                    if (rid >= total_rows) continue;
-                    c = rid / rows_per_col; pos = ((rid % rows_per_col) << W) + pe; K = (u32)(((rid % rows_per_col) << W) + e);
+                    u32 rid = row032 + t;
+                    if (rid >= total32) continue;
+                    c = rid >> kW; pos = ((rid & rpc_mask) << W) + pe; K = ((rid & rpc_mask) << W) + e;
                 } else {
                     c = col;
-                    u32 inner = (u32)(base & (((size_t)1 << S) - 1)) + t;
-                    pos = ((size_t)bitrev_u32(inner, S) << W) + pe; K = (e << S) + inner;
+                    u32 inner = (base32 & ((1u << S) - 1)) + t;
+                    pos = (bitrev_u32(inner, S) << W) + pe; K = (e << S) + inner;
                 }
-                if (p.postA) v = gl_mul(v, tab2(p.postA, p.postB, K));      // exact products: the permuting pass rarely has an output scale
-                if (p.post_const) v = gl_mul(v, p.post_const);
+                if (decltype(POST)::value) {
+                    if (p.postA) v = gl_mul(v, tab2(p.postA, p.postB, K));      // exact products: the permuting pass rarely has an output scale
+                    if (p.post_const) v = gl_mul(v, p.post_const);
+                }
                 p.out[c * p.out_stride + pos] = v;
             }
-        }
+        };
+        if (p.postA || p.post_const) scatter(std::true_type{}); else scatter(std::false_type{});
         return;
     }
     if (!DIT && ROW && LAST_DIF != 0) { __syncthreads(); to_lds(LAST_DIF); __syncthreads(); from_lds(0); smap = 0; }
@@ -317,19 +333,21 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
         u64 f[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) f[q] = 1;
-        if (act && need_mul) {
+        // as on the load side: the factor source is decided once per workgroup (mode 1: table, 2: two-level tables)
+        auto factors = [&](auto MODE) {
+            if (!act) return;
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 u32 t, slot; map_any(smap, q, t, slot);
-                size_t c, pos;
+                size_t c; u32 pos;
                 if (!gpos(t, slot, c, pos)) continue;
-                if (p.store_tab) f[q] = p.store_tab[pos];
+                if (decltype(MODE)::value == 1) f[q] = p.store_tab[pos];
                 else {
                     const u32 e = DIT ? slot : bitrev_u32(slot, W);
                     u64 g1 = 1; bool have = false;
-                    if (!DIT && S > 0) { u32 inner = (u32)(pos & (((size_t)1 << S) - 1)); g1 = tab2(p.twA, p.twB, e * inner); have = true; }
+                    if (!DIT && S > 0) { u32 inner = pos & ((1u << S) - 1); g1 = tab2(p.twA, p.twB, e * inner); have = true; }
                     if (p.postA) {
-                        u32 K = ROW ? (u32)(((pos >> W) << W) + e) : (u32)(((base >> (W + S)) << (W + S)) + ((size_t)e << S) + (pos & (((size_t)1 << S) - 1)));
+                        u32 K = ROW ? (((pos >> W) << W) + e) : (u32)(((base >> (W + S)) << (W + S)) + ((size_t)e << S) + (pos & ((1u << S) - 1)));
                         u64 g2 = tab2(p.postA, p.postB, K);
                         g1 = have ? gl_mul(g1, g2) : g2; have = true;
                     }
@@ -337,16 +355,19 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                     f[q] = g1;
                 }
             }
-        }
+        };
+        if (need_mul) { if (p.store_tab) factors(std::integral_constant<int, 1>{}); else factors(std::integral_constant<int, 2>{}); }
+        if (wact && need_mul) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            u64 v = x[q];
-            if (wact && need_mul) v = fx.mul(v, f[q]);
-            if (act) {
+            for (int q = 0; q < 16; q++) f[q] = fx.mul(x[q], f[q]);            // f now holds the values to store
+        }
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
                 u32 t, slot; map_any(smap, q, t, slot);
-                size_t c, pos;
+                size_t c; u32 pos;
                 if (!gpos(t, slot, c, pos)) continue;
-                p.out[c * p.out_stride + pos] = v;
+                p.out[c * p.out_stride + pos] = need_mul ? f[q] : x[q];
             }
         }
     };
@@ -368,7 +389,7 @@ __global__ void build_pass_table_kernel(PassParams p, int dit, int store, u64 *o
     u32 slot = (u32)((pos >> S) & (((size_t)1 << W) - 1)), inner = (u32)(pos & (((size_t)1 << S) - 1));
     u64 f = 1;
     if (!store) {
-        if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32((u32)pos, p.k) : (u32)pos; f = gl_mul(f, tab2(p.preA, p.preB, j)); }
+        if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32(pos, p.k) : pos; f = gl_mul(f, tab2(p.preA, p.preB, j)); }
         if (dit && S > 0) f = gl_mul(f, tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner));
     } else {
         u32 e = dit ? slot : bitrev_u32(slot, W);
@@ -416,7 +437,8 @@ static bool launch_dr(zk_ctx *ctx, const PassParams &p, const char *name) {
     }
 }
 bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, const char *name) {
-    if (p0.W < 4 || p0.W > 10 || p0.W + p0.TL > 13 || !p0.tw_full) return false;
+    if (p0.W < 4 || p0.W > 10 || p0.W + p0.TL > 13 || !p0.tw_full || p0.k > 30) return false;
+    if (((((size_t)1 << p0.k) >> p0.W) * (size_t)p0.n_cols + 64) >> 32) return false;      // the kernel numbers rows in 32 bits
     PassParams p = p0;
     p.force_redo = (int)ctx->force_redo;
     bool need_load = p.preA || (dit && p.S > 0);

@@ -102,6 +102,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         if (tables[t].air->n_public_inputs && !tables[t].public_inputs) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: public inputs missing");
     }
     hipSetDevice(ctx->device);
+    ctx->wait_pending_uploads();                     // traces prefetched with zk_trace_upload_async (device-side wait)
     const u32 nch = cfg.num_challenges, capw = 4u << cfg.cap_height;
     std::vector<TableLayout> lay(nt);
     size_t total = 2;
@@ -181,9 +182,9 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         else {
             u64 *d = (u64 *)A_(n * C * sizeof(u64));
             if (!d) { rc = ZK_ERR_OOM; break; }
-            // host-resident trace (pageable memory of the caller): copy and wait, see zk_ctx::h_stage
-            if (hipMemcpyAsync(d, tables[t].trace, n * C * sizeof(u64), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ZK_ERR_HIP; break; }
+            // host-resident trace: pinned memory (zk_host_alloc) goes up with one asynchronous copy on this stream, pageable
+            // memory through the context's two pinned chunks; no host wait either way (zk_ctx::upload_large)
+            if ((rc = ctx->upload_large(d, tables[t].trace, n * C * sizeof(u64), ctx->stream)) != ZK_OK) break;
             d_trace[t] = d;
         }
         rc = zk_batch_commit_dev(ctx, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);

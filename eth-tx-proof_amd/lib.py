@@ -183,6 +183,32 @@ class Context:
         return Challenger(self)
 
 
+def pinned_empty(ctx, shape, dtype=np.uint64):
+    """numpy array in pinned host memory (zk_host_alloc): traces held here are uploaded by zk_prove_tables with one asynchronous
+    copy at PCIe rate.  The memory is freed when the array (and every view of it) is gone."""
+    import weakref
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    ctx._chk(lib().zk_host_alloc(ctx.h, C.c_size_t(n), C.byref(p)), "zk_host_alloc")
+    buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    L, addr = lib(), p.value
+
+    def _free():
+        if ctx.h:                                   # a closed context has nothing to free through: the runtime reclaims at exit
+            L.zk_host_free(ctx.h, C.c_void_p(addr))
+    weakref.finalize(buf, _free)
+    return arr
+
+
+def trace_upload_async(ctx, trace):
+    """zk_trace_upload_async: start uploading a host trace on the context's copy stream; returns the device pointer (int)."""
+    trace = np.ascontiguousarray(trace, dtype=np.uint64) if not (isinstance(trace, np.ndarray) and trace.dtype == np.uint64 and trace.flags.c_contiguous) else trace
+    d = C.c_void_p()
+    ctx._chk(lib().zk_trace_upload_async(ctx.h, trace.ctypes.data_as(C.c_void_p), C.c_size_t(trace.size), C.byref(d)), "zk_trace_upload_async")
+    return d.value
+
+
 class Batch:
     """zk_batch: PolynomialBatch::{from_values, from_coeffs}; device resident."""
 
@@ -306,7 +332,8 @@ def _tables(items):
             arr[i].trace_on_device = 1
             arr[i].trace = int(trace)
         else:
-            trace = _u64(trace)
+            if not (isinstance(trace, np.ndarray) and trace.dtype == np.uint64 and trace.flags.c_contiguous):
+                trace = _u64(trace)                 # (a pinned array passes through untouched: same address, no copy)
             assert trace.shape == (prog.n_trace_cols, 1 << log_n)
             keep.append(trace)
             arr[i].trace_on_device = 0

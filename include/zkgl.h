@@ -69,6 +69,18 @@ int32_t zk_dev_free(zk_ctx *ctx, void *d_ptr);
 int32_t zk_dev_upload(zk_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 int32_t zk_dev_download(zk_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 
+/* Host buffers the GPU can read at full PCIe rate.  A witness held in memory from zk_host_alloc (pinned) is uploaded by
+ * zk_prove_tables with one asynchronous copy on the context's stream -- no staging, no host wait; traces of other in-flight
+ * contexts keep the chip busy meanwhile.  Ordinary (pageable) host memory is accepted everywhere too: it is then staged through
+ * two pinned chunks of the context (the CPU fills one while the DMA engine drains the other). */
+int32_t zk_host_alloc(zk_ctx *ctx, size_t bytes, void **h_ptr);
+int32_t zk_host_free(zk_ctx *ctx, void *h_ptr);
+/* Prefetch for a single worker: start uploading the NEXT unit's trace (n_words u64, pinned or pageable) on the context's copy
+ * stream and return at once; *d_ptr is device memory owned by the context (zk_dev_free it after the proof).  The next call on this
+ * context that enqueues work (e.g. zk_prove_tables with trace_on_device = 1 and this pointer) first waits, on the device, for
+ * every pending upload.  Call it BEFORE the zk_prove_tables of the current unit so that the copy overlaps that proof. */
+int32_t zk_trace_upload_async(zk_ctx *ctx, const uint64_t *trace, size_t n_words, uint64_t **d_ptr);
+
 /* ------------------------------------------------------------------ field / NTT
  * plonky2_field::fft::{fft_with_options, ifft_with_options}, PolynomialCoeffs::coset_fft_with_options,
  * PolynomialValues::coset_ifft.  Natural order in, natural order out, in place, n_cols independent columns.
