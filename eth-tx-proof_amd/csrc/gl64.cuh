@@ -154,6 +154,26 @@ template <bool EXACT> struct glx {
         u64 A4 = gl_madd1((u32)(X >> 32), (u64)a1 * b1);
         return tail((X << 32) | (u32)P0, A4, cy);
     }
+    // the same product as a WEAK residue (any representative below 2^64; the borrow repair is still flagged): for values that stay
+    // inside a weak-arithmetic network and are checked once at its end (check_canon)
+    __device__ __forceinline__ u64 mulw(u64 a, u64 b) {
+        if (EXACT) return gl_mul(a, b);
+        u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+        u64 P0 = (u64)a0 * b0;
+        u64 A2 = gl_madd1((u32)(P0 >> 32), (u64)a0 * b1);
+        u64 X, cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(X), "=s"(cy) : "v"(a1), "v"(b0), "v"(A2));
+        u64 A4 = gl_madd1((u32)(X >> 32), (u64)a1 * b1);
+        u64 r = gl_mad_eps((u32)A4, (X << 32) | (u32)P0);
+        u32 rl = (u32)r, rh = (u32)(r >> 32), h1 = (u32)(A4 >> 32), dl, dh;
+        asm("v_subb_co_u32 %[dl], vcc, %[rl], %[h], %[cy]\n\t"
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32 %[dh], vcc, 0, %[rh], vcc\n\t"
+            "s_or_b64 %[fl], %[fl], vcc\n\t"
+            : [dl] "=&v"(dl), [dh] "=&v"(dh), [fl] "+s"(fl)
+            : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h1), [cy] "s"(cy) : "vcc");
+        return ((u64)dh << 32) | dl;
+    }
     // lo + hi*2^64 - cy  ->  canonical residue unless a rare repair was skipped (then fl != 0)
     __device__ __forceinline__ u64 tail(u64 lo, u64 hi, u64 cy) {
         u64 r = gl_mad_eps((u32)hi, lo);

@@ -33,22 +33,22 @@ __device__ __forceinline__ void radix_net(G &g, u64 (&x)[16], const int g0, cons
             const int e1 = ((i1 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);            // twiddle as a power of w_16
             if (Q == 1) {
                 // (a single butterfly per layer only in the radix-2 tail phase)
-                if (DIT && e1) x[g0 + j1] = g.mul(x[g0 + j1], tw16[e1]);
+                if (DIT && e1) x[g0 + j1] = g.mulw(x[g0 + j1], tw16[e1]);
                 g.bfly1(x[g0 + i1], x[g0 + j1]);
-                if (!DIT && e1) x[g0 + j1] = g.mul(x[g0 + j1], tw16[e1]);
+                if (!DIT && e1) x[g0 + j1] = g.mulw(x[g0 + j1], tw16[e1]);
                 continue;
             }
             const int b1 = b0 + 1;
             const int i2 = ((b1 >> h) << (h + 1)) | (b1 & ((1 << h) - 1)), j2 = i2 + (1 << h);
             const int e2 = ((i2 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);
             if (DIT) {
-                if (e1) x[g0 + j1] = g.mul(x[g0 + j1], tw16[e1]);
-                if (e2) x[g0 + j2] = g.mul(x[g0 + j2], tw16[e2]);
+                if (e1) x[g0 + j1] = g.mulw(x[g0 + j1], tw16[e1]);
+                if (e2) x[g0 + j2] = g.mulw(x[g0 + j2], tw16[e2]);
             }
             g.bfly2(x[g0 + i1], x[g0 + j1], x[g0 + i2], x[g0 + j2]);
             if (!DIT) {
-                if (e1) x[g0 + j1] = g.mul(x[g0 + j1], tw16[e1]);
-                if (e2) x[g0 + j2] = g.mul(x[g0 + j2], tw16[e2]);
+                if (e1) x[g0 + j1] = g.mulw(x[g0 + j1], tw16[e1]);
+                if (e2) x[g0 + j2] = g.mulw(x[g0 + j2], tw16[e2]);
             }
         }
     }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
         }
         if (wact && need_mul) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) x[q] = fx.mul(x[q], f[q]);
+            for (int q = 0; q < 16; q++) x[q] = fx.mulw(x[q], f[q]);
         }
     }
     __syncthreads();            // shRW is complete (the data loads above were in flight meanwhile)
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             if (W > 4) {
                 u32 t, slot; map_H(0, t, slot); const u32 r = slot;          // slot of register 0 == r
 #pragma unroll
-                for (int q = 1; q < 16; q++) x[q] = fx.mul(x[q], shRW[act ? BR<4>::rev(q) * r : 0]);
+                for (int q = 1; q < 16; q++) x[q] = fx.mulw(x[q], shRW[act ? BR<4>::rev(q) * r : 0]);
             }
         }
         if (P2 > 0) {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                         if (i == 0) continue;
                         u32 t, slot; map_M(q, t, slot);
                         u32 lo = slot & ((1u << P3) - 1);
-                        x[q] = fx.mul(x[q], shRW[act ? (BR<P2>::rev(i) * lo) << 4 : 0]);
+                        x[q] = fx.mulw(x[q], shRW[act ? (BR<P2>::rev(i) * lo) << 4 : 0]);
                     }
                 }
             }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                     const int i = q & ((1 << P3) - 1);
                     if (i == 0) continue;
                     u32 t, slot; map_L(q, t, slot);
-                    x[q] = fx.mul(x[q], shRW[act ? (u32)i * bitrev_u32(slot >> P3, W - P3) : 0]);
+                    x[q] = fx.mulw(x[q], shRW[act ? (u32)i * bitrev_u32(slot >> P3, W - P3) : 0]);
                 }
             }
             to_lds(2); __syncthreads(); from_lds(1);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
                     if (i == 0) continue;
                     u32 t, slot; map_M(q, t, slot);
                     u32 hi = slot >> (P2 + P3);
-                    x[q] = fx.mul(x[q], shRW[act ? ((u32)i * bitrev_u32(hi, 4)) << P3 : 0]);
+                    x[q] = fx.mulw(x[q], shRW[act ? ((u32)i * bitrev_u32(hi, 4)) << P3 : 0]);
                 }
             }
             to_lds(1); __syncthreads(); from_lds(0);

@@ -275,3 +275,34 @@ def test_north_star_target_2_23_rows_unit_proof_verifies(zk, orc):
         assert (zk.prove_tables(c, cfg, items) == proof).all()
     finally:
         c.close()
+
+
+def test_host_resident_traces_pinned_pageable_and_prefetched_give_the_same_proof(zk, orc):
+    """The PCIe-inclusive entry: a host-resident trace in pinned memory (zk_host_alloc: one asynchronous copy), in pageable memory
+    (staged through the context's two pinned chunks; 2^17 x 93 x 8 B = 97 MB spans several 32 MB chunks) and prefetched on the
+    copy stream (zk_trace_upload_async) must all give the proof of the device-resident trace, which the oracle's verifier accepts."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(93, 19)
+    log_n = 17
+    c = zk.Context(0)
+    try:
+        d, pub = zk.synth_trace_dev(c, 93, log_n, 0x5EED0017)
+        ref = zk.prove_tables(c, cfg, [(prog, log_n, d, pub)]).copy()
+        assert orc.verify(cfg, [(prog, log_n, None, pub)], ref) == 0
+        pageable = c.download(d, (93, 1 << log_n))
+        pinned = zk.pinned_empty(c, (93, 1 << log_n))
+        pinned[...] = pageable
+        assert (zk.prove_tables(c, cfg, [(prog, log_n, pageable, pub)]) == ref).all()
+        assert (zk.prove_tables(c, cfg, [(prog, log_n, pinned, pub)]) == ref).all()
+        # single-worker double buffering: upload unit k+1 while unit k is proved
+        d2 = zk.trace_upload_async(c, pinned)
+        p_a = zk.prove_tables(c, cfg, [(prog, log_n, pageable, pub)]).copy()
+        d3 = zk.trace_upload_async(c, pageable)
+        p_b = zk.prove_tables(c, cfg, [(prog, log_n, d2, pub)]).copy()
+        p_c = zk.prove_tables(c, cfg, [(prog, log_n, d3, pub)]).copy()
+        assert (p_a == ref).all() and (p_b == ref).all() and (p_c == ref).all()
+        c.dev_free(d2); c.dev_free(d3); c.dev_free(d)
+        del pinned
+    finally:
+        c.close()
