@@ -86,7 +86,32 @@ int32_t zk_ctx::upload_large(void *d_dst, const void *src, size_t bytes, hipStre
     if (!bytes) return ZK_OK;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, src) == hipSuccess && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged)) {
-        // pinned (or device) source: one asynchronous copy, the caller keeps the buffer alive until the work has been waited for
+        // pinned (or device) source: asynchronous copies, the caller keeps the buffer alive until the work has been waited for.
+        // One stream's copies run on one DMA engine (about half of what the PCIe link carries): a large upload is cut into four
+        // parts, three of them on side streams that start behind `on` and that `on` waits for afterwards.
+        static const int parts_env = getenv("ZK_UPLOAD_PARTS") ? atoi(getenv("ZK_UPLOAD_PARTS")) : 4;
+        const int parts = (bytes >= ((size_t)64 << 20) && parts_env > 1) ? (parts_env > 4 ? 4 : parts_env) : 1;
+        if (parts > 1) {
+            for (int i = 0; i < parts - 1; i++)
+                if (!part_stream[i] && hipStreamCreateWithFlags(&part_stream[i], hipStreamNonBlocking) != hipSuccess) { part_stream[i] = nullptr; return fail(ZK_ERR_HIP, "upload_large: side stream"); }
+            auto get_event = [&]() { if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; } hipEvent_t e = nullptr; hipEventCreate(&e); return e; };
+            hipEvent_t start = get_event();
+            if (!start || hipEventRecord(start, on) != hipSuccess) return fail(ZK_ERR_HIP, "upload_large: event");
+            const size_t per = ((bytes / parts) + 4095) & ~(size_t)4095;
+            for (int i = 0; i < parts; i++) {
+                const size_t off = (size_t)i * per, len = i == parts - 1 ? bytes - off : per;
+                hipStream_t st = i == 0 ? on : part_stream[i - 1];
+                if (i && hipStreamWaitEvent(st, start, 0) != hipSuccess) return fail(ZK_ERR_HIP, "upload_large: ordering");
+                if (hipMemcpyAsync((char *)d_dst + off, (const char *)src + off, len, hipMemcpyDefault, st) != hipSuccess) return fail(ZK_ERR_HIP, "upload_large: hipMemcpyAsync");
+                if (i) {
+                    hipEvent_t done = get_event();
+                    if (!done || hipEventRecord(done, st) != hipSuccess || hipStreamWaitEvent(on, done, 0) != hipSuccess) return fail(ZK_ERR_HIP, "upload_large: join");
+                    event_pool.push_back(done);
+                }
+            }
+            event_pool.push_back(start);
+            return ZK_OK;
+        }
         if (hipMemcpyAsync(d_dst, src, bytes, hipMemcpyDefault, on) != hipSuccess) return fail(ZK_ERR_HIP, "upload_large: hipMemcpyAsync");
         return ZK_OK;
     }
@@ -193,6 +218,7 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_out) hipHostFree(c->h_out);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+    for (int i = 0; i < 3; i++) if (c->part_stream[i]) { hipStreamSynchronize(c->part_stream[i]); hipStreamDestroy(c->part_stream[i]); }
     for (hipEvent_t e : c->pending_uploads) hipEventDestroy(e);
     for (int i = 0; i < 2; i++) { if (c->h_chunk[i]) hipHostFree(c->h_chunk[i]); if (c->chunk_free[i]) hipEventDestroy(c->chunk_free[i]); }
     if (c->own_stream) hipStreamDestroy(c->stream);

@@ -47,25 +47,28 @@ __device__ __forceinline__ psdm_v4i bfrag(u64 w0, u64 w1) {
     b[2] = (int)((u32)w1 ^ 0x80808080u); b[3] = (int)((u32)(w1 >> 32) ^ 0x80808080u);
     return b;
 }
-// sum_a u_a 2^(8a), u_a < 2^25, as a weak residue: two 4-term multiply-add chains (low and high half), then
-// AL + AH*2^32 = low64 + high*2^64 with high < 2^27 -> low + high*eps.  The multipliers 1, 2^8, 2^16, 2^24 are handed over as
-// opaque wave-uniform values (struct rk): hipcc then emits one v_mad_u64_u32 per term, whereas with visible constants it
-// builds zero-extend + 64-bit shift + add (three instructions per term).  They stay compiler-generated instructions on
-// purpose: the first reader of a matrix-core result must be visible to the hazard recognizer (an inline-asm reader is not).
+// sum_a u_a 2^(8a) as a weak residue, every limb sum u_a below 2^24 - 2^16 (poseidon_mfma_tables.h, OFF_LOG).
+// Limbs are paired with 32-bit shift-adds (u_a + 2^8 u_{a+1} < 2^32), pairs joined by one v_mad_u64_u32 (x 2^16): AL, AH < 2^49.
+// AL + AH 2^32 = AL + AH.hi 2^64 + AH.lo 2^32  ->  (AL + AH.hi * eps) cannot overflow (both terms < 2^49); adding AH.lo into the high
+// word may wrap once: + eps.  10 vector instructions per word (was 13).  The multipliers are handed over as opaque wave-uniform
+// values (struct rk) so that hipcc emits one v_mad_u64_u32 per product instead of zero-extend + shift + add.  The first readers of
+// a matrix-core result stay compiler-generated instructions on purpose: they must be visible to the hazard recognizer (an
+// inline-asm reader is not).
 struct rk {
-    u32 k0, k8, k16, k24;
+    u32 k16, keps;
     __device__ __forceinline__ void init() {
-        k0 = 1u; k8 = 1u << 8; k16 = 1u << 16; k24 = 1u << 24;
-        asm("" : "+s"(k0), "+s"(k8), "+s"(k16), "+s"(k24));
+        k16 = 1u << 16; keps = 0xFFFFFFFFu;
+        asm("" : "+s"(k16), "+s"(keps));
     }
 };
 __device__ __forceinline__ u64 recombine(const rk &K, u32 u0, u32 u1, u32 u2, u32 u3, u32 u4, u32 u5, u32 u6, u32 u7) {
-    u64 AL = (u64)u3 * K.k24; AL += (u64)u2 * K.k16; AL += (u64)u1 * K.k8; AL += (u64)u0 * K.k0;
-    u64 AH = (u64)u7 * K.k24; AH += (u64)u6 * K.k16; AH += (u64)u5 * K.k8; AH += (u64)u4 * K.k0;
-    u32 th, cy;
-    th = __builtin_addc((u32)(AL >> 32), (u32)AH, 0u, &cy);
-    u32 high = (u32)(AH >> 32) + cy;
-    return gl_mad_eps(high, ((u64)th << 32) | (u32)AL);
+    const u32 t0 = (u1 << 8) + u0, t1 = (u3 << 8) + u2, t2 = (u5 << 8) + u4, t3 = (u7 << 8) + u6;     // v_lshl_add_u32
+    const u64 AL = (u64)t1 * K.k16 + t0, AH = (u64)t3 * K.k16 + t2;
+    const u64 r = (u64)(u32)(AH >> 32) * K.keps + AL;
+    u32 rh, cy;
+    rh = __builtin_addc((u32)(r >> 32), (u32)AH, 0u, &cy);
+    const u64 w = ((u64)rh << 32) | (u32)r;
+    return w + (cy ? GL_EPS : 0ull);
 }
 __device__ __forceinline__ void recombine2(const rk &K, const psdm_v16i &acc, u64 &o0, u64 &o1) {
     o0 = recombine(K, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);

@@ -46,7 +46,10 @@ namespace psdm_host {
 #define PSD_CONST static const
 #include "poseidon_constants.inc"
 
-static const uint32_t OFF_LOG = 24;    // accumulators lie in (-2^23.3, 2^23.3) for K <= 288 signed-byte products
+// The accumulators of K <= 288 signed-byte products lie within +-288 * 2^14 = +-2^22.17; started at 2^23 (plus the constant's byte)
+// every limb sum u stays in (2^21.8, 2^23.66): below 2^24 - 2^16, which is what lets the recombination pair limbs with 32-bit
+// shift-adds (u_a + 2^8 u_{a+1} < 2^32, poseidon_mfma.cuh recombine).
+static const uint32_t OFF_LOG = 23;
 
 // eight signed base-256 digits (-128..127) of a representative of c (mod p).  Eight such digits cover
 // [-128 (2^64-1)/255, 127 (2^64-1)/255]: c itself up to 0x7F7F7F7F7F7F7F7F, c - p above (c - p > -128 (2^64-1)/255 there).

@@ -7,6 +7,7 @@
 //   generate_txn_proof(p_state(), input, None)       /root/reference/ops/src/lib.rs:52
 // up to (not including) the Plonk recursion wrappers.  Witness generation (generate_traces, a CPU EVM
 // interpreter upstream) is out of scope: traces are an input.
+#include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <mutex>
@@ -25,6 +26,23 @@ __global__ void zeta_kernel(u64 *zeta /* in: zeta; out: +2 = g_n * zeta */, u32 
 }
 __global__ void take_re_kernel(const u64 *ext, u32 n, u64 *out) { u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = ext[2 * i]; }
 __global__ void copy_words2_kernel(const u64 *src, u64 *dst, u32 n) { u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
+
+// Debugging aid (env ZK_DEBUG_SCRATCH_PROBE=1, tools/stress_faults.py): a kernel that deliberately lives in scratch (a dynamically
+// indexed private array), launched between the real kernels of every proof on every stream -- the situation in which round 1 saw
+// GPU memory faults with spilling kernels.  Writes a checksum nobody reads.
+__global__ __launch_bounds__(256) void scratch_probe_kernel(u64 *out, u32 rounds) {
+    u64 a[192];
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (u32 i = 0; i < 192; i++) a[i] = (u64)tid * 0x9E3779B97F4A7C15ULL + i;
+    u32 j = tid % 191;
+    u64 acc = 0;
+    for (u32 r = 0; r < rounds; r++) { acc += a[j]; a[(j * 7 + r) % 192] ^= acc; j = (u32)(acc % 191); }
+    if (acc == 0x123456789ULL) out[0] = acc;         // never true in practice; keeps the loop alive
+}
+static void scratch_probe(zk_ctx *ctx, u64 *d_sink) {
+    static const int on = getenv("ZK_DEBUG_SCRATCH_PROBE") ? atoi(getenv("ZK_DEBUG_SCRATCH_PROBE")) : 0;
+    if (on) ZK_LAUNCH(ctx, "scratch_probe", scratch_probe_kernel, dim3(2048), dim3(256), 0, d_sink, 64u);
+}
 
 struct TableLayout { size_t base, o_trace_cap, o_aux_cap, o_quot_cap; FriLayout fri; size_t end; };
 
@@ -82,7 +100,8 @@ extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uin
                                    uint64_t *proof_out, size_t cap_words, size_t *len_words) {
     static std::atomic<bool> warm{false};
     static std::mutex cold_mu;
-    if (warm.load(std::memory_order_acquire)) return prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
+    static const bool no_cold = getenv("ZK_NO_COLD_MUTEX") && atoi(getenv("ZK_NO_COLD_MUTEX"));     // stress runs: workaround off
+    if (no_cold || warm.load(std::memory_order_acquire)) return prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
     std::lock_guard<std::mutex> lk(cold_mu);
     int32_t rc = prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
     if (rc == ZK_OK) warm.store(true, std::memory_order_release);
@@ -189,6 +208,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         }
         rc = zk_batch_commit_dev(ctx, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);
         if (rc) break;
+        scratch_probe(ctx, d_zeta + 7);
         ZK_LAUNCH(ctx, "copy_words", copy_words2_kernel, g1(capw), dim3(256), 0, trace_b[t]->cap(), d_proof + lay[t].o_trace_cap, capw);
         TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + lay[t].o_trace_cap; a.op[0].n = capw;
         zk_transcript_run(ctx, ch, a);
@@ -226,6 +246,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         if (rc == ZK_OK) rc = zk_batch_commit_dev(ctx, d_q, log_n, Q, cfg.rate_bits, cfg.cap_height, 0, &quot_b[t]);
         ctx->release(d_q);
         if (rc) break;
+        scratch_probe(ctx, d_zeta + 7);
         ZK_LAUNCH(ctx, "copy_words", copy_words2_kernel, g1(capw), dim3(256), 0, quot_b[t]->cap(), d_proof + y.o_quot_cap, capw);
         { TOpList a = {}; a.n = 2; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + y.o_quot_cap; a.op[0].n = capw;
           a.op[1].kind = TOP_GET; a.op[1].dst = d_zeta; a.op[1].n = 2; zk_transcript_run(ctx, ch, a); }

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -158,9 +159,9 @@ extern "C" int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_cha
 // mode -1: never; 0 (default): only kernels compiled ahead of time by zk_prover_state_prepare; 1: compile at first use for tables
 // with >= 2^min_log coset points; 2: compile at first use, always
 bool zk_quotient_jit_enabled(const zk_ctx *ctx, size_t L) {
-    if (ctx->quotient_jit_mode == 2) return true;
+    if (ctx->quotient_jit_mode == 2 || ctx->quotient_aot) return true;   // kernels built with the library cost nothing to use: any size
     if (L < ((size_t)1 << ctx->quotient_jit_min_log)) return false;
-    return ctx->quotient_jit_mode >= 0 || ctx->quotient_aot;       // ahead-of-time kernels need no run-time compiler
+    return ctx->quotient_jit_mode >= 0;
 }
 
 static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k);
@@ -181,6 +182,7 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
         }
     }
     if (ctx->quotient_jit_mode < 0) return ZK_JIT_UNAVAILABLE;
+    if (ctx->quotient_jit_mode != 2 && p.L < ((size_t)1 << ctx->quotient_jit_min_log)) return ZK_JIT_UNAVAILABLE;   // too small to pay for hiprtc
     JitKernel k;
     int32_t rc = jit_get(ctx, air, C, A, nch, rate_bits, ctx->quotient_jit_mode >= 1, k);
     if (rc != ZK_OK) return rc;
@@ -216,6 +218,58 @@ extern "C" int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *c
     return ZK_OK;
 }
 
+// ---- on-disk cache of compiled kernels (see zk_prover_state_cache_dir in include/zkgl.h)
+namespace {
+std::string g_cache_dir; bool g_cache_dir_set = false;
+uint64_t g_n_compiled = 0, g_n_loaded = 0;
+struct CoHeader { char magic[8]; uint32_t version, key_len; uint64_t code_len, checksum; };     // then key bytes, then code bytes
+const char CO_MAGIC[8] = {'Z', 'K', 'G', 'L', 'C', 'O', '0', '1'};
+const std::string &cache_dir() {                       // g_mu held
+    if (!g_cache_dir_set) { const char *e = getenv("ZK_PROVER_STATE_DIR"); g_cache_dir = e ? e : ""; g_cache_dir_set = true; }
+    return g_cache_dir;
+}
+std::string co_path(const std::string &key) {
+    char name[96]; snprintf(name, sizeof name, "/prover_state_%016llx.gfx950.co", (unsigned long long)fnv1a(key));
+    return cache_dir() + name;
+}
+bool co_load(const std::string &key, std::vector<char> &code) {
+    if (cache_dir().empty()) return false;
+    FILE *f = fopen(co_path(key).c_str(), "rb");
+    if (!f) return false;
+    CoHeader h; bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, CO_MAGIC, 8) && h.version == 1 && h.key_len == key.size() &&
+                          h.code_len > 0 && h.code_len < ((uint64_t)1 << 30);
+    std::string k2;
+    if (ok) { k2.resize(h.key_len); ok = fread(&k2[0], 1, h.key_len, f) == h.key_len && k2 == key; }
+    if (ok) { code.resize(h.code_len); ok = fread(code.data(), 1, h.code_len, f) == h.code_len && fgetc(f) == EOF; }
+    fclose(f);
+    if (ok) ok = fnv1a(std::string(code.data(), code.size())) == h.checksum;
+    if (!ok) fprintf(stderr, "[zkgl] prover state file %s is unusable, rebuilding\n", co_path(key).c_str());
+    return ok;
+}
+void co_store(const std::string &key, const std::vector<char> &code) {
+    if (cache_dir().empty()) return;
+    const std::string path = co_path(key), tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) { fprintf(stderr, "[zkgl] cannot create prover state file %s\n", tmp.c_str()); return; }
+    CoHeader h; memcpy(h.magic, CO_MAGIC, 8); h.version = 1; h.key_len = (uint32_t)key.size(); h.code_len = code.size();
+    h.checksum = fnv1a(std::string(code.data(), code.size()));
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(key.data(), 1, key.size(), f) == key.size() && fwrite(code.data(), 1, code.size(), f) == code.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) { remove(tmp.c_str()); fprintf(stderr, "[zkgl] failed to write prover state file %s\n", path.c_str()); }
+}
+}  // namespace
+extern "C" int32_t zk_prover_state_cache_dir(const char *dir) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_cache_dir = dir ? dir : ""; g_cache_dir_set = true;
+    return ZK_OK;
+}
+extern "C" int32_t zk_prover_state_stats(uint64_t *compiled, uint64_t *loaded_from_disk) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (compiled) *compiled = g_n_compiled;
+    if (loaded_from_disk) *loaded_from_disk = g_n_loaded;
+    return ZK_OK;
+}
+
 static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k) {
     std::string key = air_key(air, C, A, nch, rate_bits);
     { u32 dev = (u32)ctx->device; key.append((const char *)&dev, sizeof dev); }
@@ -224,10 +278,17 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
         auto it = g_cache.find(key);
         if (it == g_cache.end()) {
             if (!may_compile) { k = JitKernel(); return ZK_OK; }
-            std::string src = generate(air, C, A, nch, rate_bits);
-            if (const char *dump = getenv("ZK_QUOTIENT_JIT_DUMP")) {       // debugging aid: the generated source, for offline inspection
+            // device-independent (the code object is per architecture); tied to the generator and to the field header it compiles
+            // against, so a library upgrade never runs a stale kernel
+            std::string disk_key = air_key(air, C, A, nch, rate_bits);
+            { const u64 ver[2] = {2 /* generator version */, fnv1a(GL64_SRC)}; disk_key.append((const char *)ver, sizeof ver); }
+            k.image = std::make_shared<std::vector<char>>();
+            const bool from_disk = co_load(disk_key, *k.image);
+            std::string src = from_disk ? std::string() : generate(air, C, A, nch, rate_bits);
+            if (!from_disk) if (const char *dump = getenv("ZK_QUOTIENT_JIT_DUMP")) {       // debugging aid: the generated source, for offline inspection
                 if (FILE *f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
             }
+            if (!from_disk) {
             hiprtcProgram prog;
             const char *hs[] = {GL64_SRC}, *hn[] = {"gl64.cuh"};
             if (hiprtcCreateProgram(&prog, src.c_str(), "quotient_jit.hip", 1, hs, hn) != HIPRTC_SUCCESS)
@@ -241,10 +302,13 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
                 return ctx->fail(ZK_ERR_HIP, ("quotient jit: compile failed: " + log.substr(0, 400)).c_str());
             }
             size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
-            k.image = std::make_shared<std::vector<char>>(cs);
-            std::vector<char> &code = *k.image;
-            hiprtcGetCode(prog, code.data());
+            k.image->resize(cs);
+            hiprtcGetCode(prog, k.image->data());
             hiprtcDestroyProgram(&prog);
+            co_store(disk_key, *k.image);
+            g_n_compiled++;
+            } else g_n_loaded++;
+            std::vector<char> &code = *k.image;
             if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: hipModuleLoadData failed");
             if (hipModuleGetFunction(&k.fn, k.mod, "quotient_jit") != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: kernel not found in module");
             // A generated kernel that spills to scratch is not used: with several streams in flight such kernels ended in GPU

@@ -54,9 +54,33 @@ __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpLi
             if (lane == 0) { c->n_in = 0; c->n_out = 0; }
             __syncthreads();
             break;
-        case TOP_OBSERVE:
-            for (u32 i = 0; i < o.n; i++) ch_observe(c, o.src[i]);
+        case TOP_OBSERVE: {
+            // element by element until the input buffer is empty, then whole rate-sized chunks with the sponge state kept in
+            // registers: one coalesced (prefetched) load and one permutation per 8 elements -- wide opening sets (thousands of
+            // columns) are a serial chain of permutations, so everything else must stay off that chain
+            u32 i = 0;
+            while (i < o.n && c->n_in != 0) ch_observe(c, o.src[i++]);
+            if (i + 8 <= o.n) {
+                const int l = lane & 15, gb = lane & ~15;
+                u64 st = l < 12 ? c->state[l] : 0;
+                u64 nxt = l < 8 ? gl_canon(o.src[i + l]) : 0;
+                while (i + 8 <= o.n) {
+                    const u64 cur = nxt;
+                    i += 8;
+                    if (i + 8 <= o.n && l < 8) nxt = gl_canon(o.src[i + l]);
+                    if (l < 8) st = cur;
+                    st = psdc::permute16(st, l, gb);
+                    if (l >= 12) st = 0;
+                }
+                __syncthreads();
+                if (lane < 12) c->state[lane] = st;
+                if (lane < 8) c->outbuf[lane] = st;
+                if (lane == 0) { c->n_in = 0; c->n_out = 8; }
+                __syncthreads();
+            }
+            while (i < o.n) ch_observe(c, o.src[i++]);
             break;
+        }
         case TOP_OBSERVE_BASE_AS_EXT:
             for (u32 i = 0; i < o.n; i++) { ch_observe(c, o.src[i]); ch_observe(c, 0); }
             break;

@@ -433,3 +433,15 @@ def fri_prove_instance(ctx, cfg, oracles, batches, challenger):
                                          challenger.h, _p(out), C.c_size_t(n), C.byref(ln)), "zk_fri_prove_instance")
     del keep
     return out[:ln.value]
+
+
+def prover_state_cache_dir(path):
+    """zk_prover_state_cache_dir: directory for the on-disk prover state (compiled constraint kernels); None switches it off."""
+    lib().zk_prover_state_cache_dir(None if path is None else str(path).encode())
+
+
+def prover_state_stats():
+    """(kernels compiled by hiprtc, kernels loaded from disk) in this process"""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    lib().zk_prover_state_stats(C.byref(a), C.byref(b))
+    return a.value, b.value

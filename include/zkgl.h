@@ -238,6 +238,16 @@ int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tabl
  * cached for the process; without this call proofs evaluate constraints with the bytecode interpreter.  Call from the thread
  * that created the context, before handing units to worker threads.  `trace` of the tables is not read. */
 int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables);
+/* Persistence of the compiled part of the prover state -- the counterpart of the reference's `./prover_state_<digest>` file
+ * (/root/reference/common/src/prover_state/persistence.rs:40-88, name from get_configuration_digest,
+ * /root/reference/common/src/prover_state/circuit.rs:177-197).  With a cache directory set (this call, or the environment variable
+ * ZK_PROVER_STATE_DIR read at first use; NULL or "" switches persistence off), every constraint kernel that hiprtc compiles is
+ * written to  <dir>/prover_state_<digest>.gfx950.co  where <digest> names the AIR (program, column counts, challenges,
+ * rate_bits), and a later process start loads the code object from there instead of compiling.  A file that is missing, truncated,
+ * for another program or fails its checksum is ignored and rebuilt (the reference warns and regenerates likewise).  Process-wide.
+ * zk_prover_state_stats: kernels compiled by hiprtc / loaded from disk so far in this process. */
+int32_t zk_prover_state_cache_dir(const char *dir);
+int32_t zk_prover_state_stats(uint64_t *compiled, uint64_t *loaded_from_disk);
 /* Build-time half of the same idea (upstream's constraints are Rust code monomorphised when the prover is built): the HIP source of
  * the constraint kernel of one AIR and the hash that names it.  Host only (no context, no GPU); tools/gen_aot_quotient.py writes
  * the kernels of the AIRs known at build time into csrc/prover_quotient_aot.hip, which is compiled with the library.

@@ -222,3 +222,49 @@ def test_quotient_jit_equals_interpreter_and_oracle(zk, orc, monkeypatch, n_cols
             assert (got == ref).all(), mode
         finally:
             c2.close()
+
+
+def test_prover_state_persists_compiled_kernels_on_disk(tmp_path):
+    """The reference keeps its prover state in ./prover_state_<digest> and loads it at the next start
+    (common/src/prover_state/persistence.rs:40-88).  Here: a first process compiles the constraint kernel of an AIR that was not
+    built with the library (hiprtc) and writes prover_state_<digest>.gfx950.co; a second process loads it without compiling and
+    produces the same proof; a truncated file is ignored and rebuilt."""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = textwrap.dedent("""
+        import json, sys, hashlib
+        sys.path.insert(0, %r)
+        import numpy as np
+        import eth_tx_proof_amd as E
+        from eth_tx_proof_amd import air, lib as zl
+        zl.prover_state_cache_dir(sys.argv[1])
+        c = zl.Context(0)
+        cfg = E.standard_fast_config()
+        prog = air.cpu_like_air(11, 3)               # not one of the shapes compiled with the library
+        d, pub = zl.synth_trace_dev(c, 11, 17, 5)
+        zl.prover_state_prepare(c, cfg, [(prog, 17, d, pub)])
+        p = zl.prove_tables(c, cfg, [(prog, 17, d, pub)])
+        comp, load = zl.prover_state_stats()
+        print(json.dumps({"compiled": comp, "loaded": load, "sha": hashlib.sha256(p.tobytes()).hexdigest()}))
+        c.close()
+    """) % root
+    script = tmp_path / "w.py"
+    script.write_text(worker)
+    cache = tmp_path / "state"
+    cache.mkdir()
+
+    def run():
+        out = subprocess.run([sys.executable, str(script), str(cache)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    first = run()
+    files = [f for f in os.listdir(cache) if f.startswith("prover_state_") and f.endswith(".gfx950.co")]
+    assert first["compiled"] == 1 and first["loaded"] == 0 and len(files) == 1
+    second = run()
+    assert second["compiled"] == 0 and second["loaded"] == 1 and second["sha"] == first["sha"]
+    path = os.path.join(cache, files[0])
+    blob = open(path, "rb").read()
+    open(path, "wb").write(blob[: len(blob) // 2])          # damaged file: ignored, rebuilt, rewritten
+    third = run()
+    assert third["compiled"] == 1 and third["loaded"] == 0 and third["sha"] == first["sha"]
+    assert open(path, "rb").read() == blob

@@ -31,7 +31,7 @@ static void emulate(int n_tiles, int n_ksteps, const int8_t *A, const int32_t *C
             for (int half = 0; half < 2; half++) {
                 u64 v = 0;
                 for (int a = 7; a >= 0; a--) {
-                    if (acc[8 * half + a] < 0 || acc[8 * half + a] >= (1L << 25)) { printf("accumulator out of range\n"); exit(1); }
+                    if (acc[8 * half + a] < 0 || acc[8 * half + a] >= (1L << 24) - (1L << 16)) { printf("accumulator out of range\n"); exit(1); }
                     v = gl_add(gl_mul(v, 256), (u64)acc[8 * half + a] % GL_P);
                 }
                 out[hp][2 * T + half] = v;
@@ -39,8 +39,39 @@ static void emulate(int n_tiles, int n_ksteps, const int8_t *A, const int32_t *C
         }
 }
 
+// worst case over EVERY operand (each signed byte at whichever end of [-128, 127] hurts most): all limb sums must stay inside
+// [0, 2^24 - 2^16), the range the 32-bit limb pairing of psdm::recombine relies on
+static int worst_case(const char *name, int n_tiles, int n_ksteps, const int8_t *A, const int32_t *Cin) {
+    long gmin = 1L << 40, gmax = -(1L << 40);
+    for (int T = 0; T < n_tiles; T++)
+        for (int m = 0; m < 32; m++) {
+            long lo = 0, hi = 0;
+            for (int ks = 0; ks < n_ksteps; ks++)
+                for (int h = 0; h < 2; h++)
+                    for (int j = 0; j < 16; j++) {
+                        const long d = A[(((size_t)T * n_ksteps + ks) * 64 + (32 * h + m)) * 16 + j];
+                        if (d > 0) { hi += 127 * d; lo -= 128 * d; } else { hi -= 128 * d; lo += 127 * d; }
+                    }
+            for (int hh = 0; hh < 2; hh++) for (int r = 0; r < 16; r++) if (rho_of(32 * hh, r) == m) {
+                const long c = Cin[((size_t)T * 2 + hh) * 16 + r];
+                if (c + lo < gmin) gmin = c + lo;
+                if (c + hi > gmax) gmax = c + hi;
+            }
+        }
+    const bool ok = gmin >= 0 && gmax < (1L << 24) - (1L << 16);
+    if (!ok) printf("%s: limb sums can reach [%ld, %ld], outside [0, 2^24 - 2^16)\n", name, gmin, gmax);
+    return ok ? 0 : 1;
+}
+
 int main() {
     static PsdmTables t; build(t);
+    {
+        int wc = 0;
+        for (int L = 0; L < 8; L++) wc += worst_case("MDS", 3, 3, &t.A_mds[0][0][0][0], &t.Cin_mds[L][0][0][0]);
+        for (int b = 0; b < 6; b++) wc += worst_case("F", 1, 3 + b, &t.A_F[b][0][0][0], &t.Cin_F[b][0][0]);
+        wc += worst_case("G2", 3, 9, &t.A_G2[0][0][0][0], &t.Cin_G2[0][0][0]);
+        if (wc) { printf("matrix-core Poseidon tables: limb range FAIL\n"); return 1; }
+    }
     u64 z = 7; int bad = 0;
     for (int trial = 0; trial < 40; trial++) {
         u64 s[12];
