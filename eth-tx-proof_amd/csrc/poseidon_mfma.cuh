@@ -65,10 +65,14 @@ __device__ __forceinline__ u64 recombine(const rk &K, u32 u0, u32 u1, u32 u2, u3
     const u32 t0 = (u1 << 8) + u0, t1 = (u3 << 8) + u2, t2 = (u5 << 8) + u4, t3 = (u7 << 8) + u6;     // v_lshl_add_u32
     const u64 AL = (u64)t1 * K.k16 + t0, AH = (u64)t3 * K.k16 + t2;
     const u64 r = (u64)(u32)(AH >> 32) * K.keps + AL;
-    u32 rh, cy;
-    rh = __builtin_addc((u32)(r >> 32), (u32)AH, 0u, &cy);
-    const u64 w = ((u64)rh << 32) | (u32)r;
-    return w + (cy ? GL_EPS : 0ull);
+    // r + AH.lo 2^32, one wrap repaired by + eps: add into the high word, carry -> mask -> x*1 + acc (the operands are results of
+    // ordinary vector instructions, not of the matrix core, so this may be inline asm)
+    u32 rl = (u32)r, rh = (u32)(r >> 32), ahl = (u32)AH, m; u64 w;
+    asm("v_add_co_u32 %[rh], vcc, %[rh], %[a]\n\t"
+        "v_cndmask_b32_e64 %[m], 0, -1, vcc\n\t"
+        : [rh] "+v"(rh), [m] "=&v"(m) : [a] "v"(ahl) : "vcc");
+    w = ((u64)rh << 32) | rl;
+    return gl_madd1(m, w);
 }
 __device__ __forceinline__ void recombine2(const rk &K, const psdm_v16i &acc, u64 &o0, u64 &o1) {
     o0 = recombine(K, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
