@@ -141,6 +141,7 @@ __device__ __forceinline__ u64 gl_madd1(u32 x, u64 acc) {
 #endif
 }
 template <bool EXACT> struct glx {
+    static constexpr bool exact = EXACT;
     u64 fl;
     // a*b = lo + hi*2^64 + cy*2^96: six v_mad_u64_u32; the mid column a0*b1 + a1*b0 keeps its carry-out as the lane mask cy
     // (2^96 = -1: it becomes the borrow-in of the last subtraction) instead of being propagated
@@ -268,6 +269,50 @@ template <bool EXACT> struct glx {
             : [a] "+v"(a), [dl] "+v"(dl), [dh] "+v"(dh), [fl] "+s"(fl), [k0] "=&s"(k0), [k1] "=&s"(k1)
             : [m0] "v"(m0), [m1] "v"(m1));
         u = a; v = ((u64)dh << 32) | dl;
+#endif
+    }
+    // x * 2^S as a weak residue, S a compile-time constant with 0 < S < 96 and S % 32 != 0 (the in-network twiddles of the radix-16
+    // NTT networks: w_16 = 2^12).  The shifted value occupies three 32-bit words at word offset q = S / 32:
+    //   q = 0:  lo64 + c 2^64                 = lo64 + c eps                                   5 instructions
+    //   q = 1:  a 2^32 + b 2^64 + c 2^96      = (a:0) + b eps - c                              8
+    //   q = 2:  a 2^64 + (c:b) 2^96           = a eps - (c:b) = (a:0) - ((c:b) + a)            8
+    // against 12 for a general product.  Rare wraps (a result below 2^32 before the last subtraction) go to the sticky word.
+    template <int S> __device__ __forceinline__ u64 mul_pow2(u64 x) {
+        static_assert(S > 0 && S < 96 && (S % 32) != 0, "shift twiddle out of range");
+        constexpr int q = S / 32, r = S % 32;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+        if (q == 0) return gl_mad_eps(x1 >> (32 - r), x << r);
+        if (q == 1) {
+            const u32 wa = x0 << r, wb = __builtin_amdgcn_alignbit(x1, x0, 32 - r), wc = x1 >> (32 - r);
+            const u64 t = gl_mad_eps(wb, (u64)wa << 32);
+            u32 tl = (u32)t, th = (u32)(t >> 32), dl, dh;
+            asm("v_sub_co_u32 %[dl], vcc, %[tl], %[h]\n\t"
+                "s_nop 1\n\t"
+                "v_subbrev_co_u32 %[dh], vcc, 0, %[th], vcc\n\t"
+                "s_or_b64 %[fl], %[fl], vcc\n\t"
+                : [dl] "=&v"(dl), [dh] "=&v"(dh), [fl] "+s"(fl) : [tl] "v"(tl), [th] "v"(th), [h] "v"(wc) : "vcc");
+            return ((u64)dh << 32) | dl;
+        }
+        {
+            const u32 wa = x0 << r;
+            const u64 T2 = gl_madd1(wa, x >> (32 - r));          // (c:b) + a < 2^(32 + r) + 2^32: no overflow
+            u32 tl = (u32)T2, th = (u32)(T2 >> 32), dl, dh, m;
+            // (a:0) - T2; a borrow means the true value is negative: + p = - eps on the wrapped difference, which is then at
+            // least 2^64 - 2^53, so the second subtraction cannot borrow (r <= 20 for every S used)
+            asm("v_sub_co_u32 %[dl], vcc, 0, %[tl]\n\t"
+                "s_nop 1\n\t"
+                "v_subb_co_u32 %[dh], vcc, %[a], %[th], vcc\n\t"
+                "s_nop 1\n\t"
+                "v_cndmask_b32_e64 %[m], 0, -1, vcc\n\t"
+                "v_sub_co_u32 %[dl], vcc, %[dl], %[m]\n\t"
+                "s_nop 1\n\t"
+                "v_subbrev_co_u32 %[dh], vcc, 0, %[dh], vcc\n\t"
+                : [dl] "=&v"(dl), [dh] "=&v"(dh), [m] "=&v"(m) : [tl] "v"(tl), [th] "v"(th), [a] "v"(wa) : "vcc");
+            return ((u64)dh << 32) | dl;
+        }
+#else
+        return 0;
 #endif
     }
     // flags a weak value that is not canonical (about one in 2^32): results headed for memory must be canonical

@@ -19,48 +19,79 @@
 
 template <int Q> struct BR { __device__ static constexpr u32 rev(u32 i) { u32 r = 0; for (int b = 0; b < Q; b++) if (i & (1u << b)) r |= 1u << (Q - 1 - b); return r; } };
 
-// radix-2^Q network on registers x[g0 .. g0 + 2^Q); tw16[j] = w_16^j (j < 8) in the pass direction
-template <int Q, bool DIT, class G>
-__device__ __forceinline__ void radix_net(G &g, u64 (&x)[16], const int g0, const u64 (&tw16)[8]) {
-    if (Q == 0) return;
-#pragma unroll
-    for (int s = 0; s < Q; s++) {
-        const int h = DIT ? s : (Q - 1 - s);
-        // the 2^(Q-1) butterflies of the layer, two per step (their carry chains interleave inside G::bfly2)
-#pragma unroll
-        for (int b0 = 0; b0 < (1 << (Q - 1)); b0 += 2) {
-            const int i1 = ((b0 >> h) << (h + 1)) | (b0 & ((1 << h) - 1)), j1 = i1 + (1 << h);
-            const int e1 = ((i1 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);            // twiddle as a power of w_16
-            if (Q == 1) {
-                // (a single butterfly per layer only in the radix-2 tail phase)
-                if (DIT && e1) x[g0 + j1] = g.mulw(x[g0 + j1], tw16[e1]);
-                g.bfly1(x[g0 + i1], x[g0 + j1]);
-                if (!DIT && e1) x[g0 + j1] = g.mulw(x[g0 + j1], tw16[e1]);
-                continue;
-            }
-            const int b1 = b0 + 1;
-            const int i2 = ((b1 >> h) << (h + 1)) | (b1 & ((1 << h) - 1)), j2 = i2 + (1 << h);
-            const int e2 = ((i2 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);
-            if (DIT) {
-                if (e1) x[g0 + j1] = g.mulw(x[g0 + j1], tw16[e1]);
-                if (e2) x[g0 + j2] = g.mulw(x[g0 + j2], tw16[e2]);
-            }
-            g.bfly2(x[g0 + i1], x[g0 + j1], x[g0 + i2], x[g0 + j2]);
-            if (!DIT) {
-                if (e1) x[g0 + j1] = g.mulw(x[g0 + j1], tw16[e1]);
-                if (e2) x[g0 + j2] = g.mulw(x[g0 + j2], tw16[e2]);
-            }
+// radix-2^Q network on registers x[g0 .. g0 + 2^Q); tw16[j] = w_16^j (j < 8) in the pass direction.
+// The twiddles inside a network are powers of w_16 = 2^12.  The exact arithmetic multiplies by the table value; the fast arithmetic
+// shifts: forward w_16^e = 2^(12e); inverse w_16^-e = 2^(192 - 12e) = -2^(96 - 12e), the sign being absorbed by the butterfly that
+// follows (DIT) or precedes (DIF) the twiddle: u +- (-t v) swaps the two outputs, (u - v)(-t) = (v - u) t swaps the two inputs.
+template <int E16, bool INV, class G> __device__ __forceinline__ u64 tw_mul(G &g, u64 v, const u64 (&tw16)[8]) {
+    if (G::exact) return g.mulw(v, tw16[E16]);
+    return g.template mul_pow2<INV ? 96 - 12 * E16 : 12 * E16>(v);
+}
+template <int Q, bool DIT, bool INV, int S, int B0, class G>
+__device__ __forceinline__ void radix_layer_step(G &g, u64 (&x)[16], const int g0, const u64 (&tw16)[8]) {
+    constexpr int h = DIT ? S : (Q - 1 - S);
+    constexpr int i1 = ((B0 >> h) << (h + 1)) | (B0 & ((1 << h) - 1)), j1 = i1 + (1 << h);
+    constexpr int e1 = ((i1 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);            // twiddle as a power of w_16
+    constexpr bool neg = INV && !G::exact;                                           // fast inverse twiddles are -2^s
+    if (Q == 1) {
+        u64 &u = x[g0 + i1], &v = x[g0 + j1];
+        if (DIT) {
+            if (e1) v = tw_mul<e1 ? e1 : 1, INV>(g, v, tw16);
+            g.bfly1(u, v);
+            if (e1 && neg) { u64 t = u; u = v; v = t; }
+        } else {
+            if (e1 && neg) { u64 t = u; u = v; v = t; g.bfly1(u, v); }
+            else g.bfly1(u, v);
+            if (e1) v = tw_mul<e1 ? e1 : 1, INV>(g, v, tw16);
         }
+        return;
+    }
+    constexpr int B1 = B0 + 1;
+    constexpr int i2 = ((B1 >> h) << (h + 1)) | (B1 & ((1 << h) - 1)), j2 = i2 + (1 << h);
+    constexpr int e2 = ((i2 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);
+    u64 &u1 = x[g0 + i1], &v1 = x[g0 + j1], &u2 = x[g0 + i2], &v2 = x[g0 + j2];
+    if (DIT) {
+        if (e1) v1 = tw_mul<e1 ? e1 : 1, INV>(g, v1, tw16);
+        if (e2) v2 = tw_mul<e2 ? e2 : 1, INV>(g, v2, tw16);
+        g.bfly2(u1, v1, u2, v2);
+        if (e1 && neg) { u64 t = u1; u1 = v1; v1 = t; }
+        if (e2 && neg) { u64 t = u2; u2 = v2; v2 = t; }
+    } else {
+        // (u, v) -> (u + v, (u - v) t): with t = -2^s feed the butterfly (v, u) and put the sum back in u's place
+        if (e1 && neg) { u64 t = u1; u1 = v1; v1 = t; }
+        if (e2 && neg) { u64 t = u2; u2 = v2; v2 = t; }
+        g.bfly2(u1, v1, u2, v2);
+        if (e1) v1 = tw_mul<e1 ? e1 : 1, INV>(g, v1, tw16);
+        if (e2) v2 = tw_mul<e2 ? e2 : 1, INV>(g, v2, tw16);
     }
 }
+template <int Q, bool DIT, bool INV, int S, int B0, class G>
+__device__ __forceinline__ void radix_layer(G &g, u64 (&x)[16], const int g0, const u64 (&tw16)[8]) {
+    if constexpr (B0 < (1 << (Q - 1))) {
+        radix_layer_step<Q, DIT, INV, S, B0>(g, x, g0, tw16);
+        radix_layer<Q, DIT, INV, S, B0 + 2>(g, x, g0, tw16);
+    }
+}
+template <int Q, bool DIT, bool INV, int S, class G>
+__device__ __forceinline__ void radix_layers(G &g, u64 (&x)[16], const int g0, const u64 (&tw16)[8]) {
+    if constexpr (S < Q) {
+        radix_layer<Q, DIT, INV, S, 0>(g, x, g0, tw16);
+        radix_layers<Q, DIT, INV, S + 1>(g, x, g0, tw16);
+    }
+}
+template <int Q, bool DIT, bool INV, class G>
+__device__ __forceinline__ void radix_net(G &g, u64 (&x)[16], const int g0, const u64 (&tw16)[8]) {
+    radix_layers<Q, DIT, INV, 0>(g, x, g0, tw16);
+}
 
-template <bool DIT, bool ROW, int W>
+template <bool DIT, bool ROW, int W, bool INV>
 __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     constexpr int P2 = (W - 4) < 4 ? (W - 4) : 4;
     constexpr int P3 = W - 4 - P2;
     constexpr int R = 1 << (W - 4);
     constexpr int G2 = 16 >> P2, G3 = 16 >> P3;
     constexpr bool SWZ = ROW && W >= 8;
+    constexpr int RS = (1 << W) + (SWZ ? (16 << P3) : 0);         // LDS row stride of a ROW tile, in elements
     extern __shared__ u64 sh[];
     const int S = p.S, TL = p.TL;
     const u32 T = 1u << TL, tid = threadIdx.x;
@@ -87,11 +118,14 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     for (int j = 0; j < 8; j++) tw16[j] = RW[j << (W - 4)];
     // the 2^W digit roots go to LDS behind the tile: the inter-phase twiddles are per-lane gathers, and an LDS gather costs a
     // fraction of an L1-hit global load's latency
-    u64 *shRW = sh + ((size_t)1 << (W + TL));
+    u64 *shRW = sh + (ROW ? ((size_t)RS << TL) : ((size_t)1 << (W + TL)));
     for (u32 i = tid; i < (1u << W); i += 512) shRW[i] = RW[i];
 
+    // ROW tiles: 2^P3 padding elements after every block of R = 2^(W-4) slots (instead of an XOR swizzle): the M-phase lanes, which
+    // walk slots R apart, then spread over the LDS banks, and -- unlike an XOR -- the padded index of register q is the thread's
+    // base plus a compile-time constant in all three mappings, so an exchange costs no address arithmetic per element.
     auto lds_idx = [&](u32 t, u32 slot) -> u32 {
-        if (ROW) { u32 s2 = SWZ ? (slot ^ ((slot >> (W - 4)) << P3)) : slot; return (t << W) + s2; }
+        if (ROW) return SWZ ? t * (u32)RS + slot + ((slot >> (W - 4)) << P3) : (t << W) + slot;
         return (slot << TL) + t;
     };
     // ---- thread <-> (t, slot) for register q in each mapping
@@ -195,7 +229,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     if (!DIT) {
         // ------------------------------------------------------------ DIF: H, M, L
         if (wact) {
-            radix_net<4, false>(fx, x, 0, tw16);
+            radix_net<4, false, INV>(fx, x, 0, tw16);
             if (W > 4) {
                 u32 t, slot; map_H(0, t, slot); const u32 r = slot;          // slot of register 0 == r
 #pragma unroll
@@ -206,7 +240,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             to_lds(0); __syncthreads(); from_lds(1);
             if (wact) {
 #pragma unroll
-                for (int g = 0; g < G2; g++) radix_net<P2, false>(fx, x, g << P2, tw16);
+                for (int g = 0; g < G2; g++) radix_net<P2, false, INV>(fx, x, g << P2, tw16);
                 if (P3 > 0) {
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
@@ -223,7 +257,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             to_lds(1); __syncthreads(); from_lds(2);
             if (wact) {
 #pragma unroll
-                for (int g = 0; g < G3; g++) radix_net<P3, false>(fx, x, g << P3, tw16);
+                for (int g = 0; g < G3; g++) radix_net<P3, false, INV>(fx, x, g << P3, tw16);
             }
         }
     } else {
@@ -232,7 +266,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
         if (P3 > 0) {
             if (wact) {
 #pragma unroll
-                for (int g = 0; g < G3; g++) radix_net<P3, true>(fx, x, g << P3, tw16);
+                for (int g = 0; g < G3; g++) radix_net<P3, true, INV>(fx, x, g << P3, tw16);
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int i = q & ((1 << P3) - 1);
@@ -246,7 +280,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
         if (P2 > 0) {
             if (wact) {
 #pragma unroll
-                for (int g = 0; g < G2; g++) radix_net<P2, true>(fx, x, g << P2, tw16);
+                for (int g = 0; g < G2; g++) radix_net<P2, true, INV>(fx, x, g << P2, tw16);
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int i = q & ((1 << P2) - 1);
@@ -258,7 +292,7 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
             }
             to_lds(1); __syncthreads(); from_lds(0);
         }
-        if (wact) radix_net<4, true>(fx, x, 0, tw16);
+        if (wact) radix_net<4, true, INV>(fx, x, 0, tw16);
     }
     // the networks work on weak residues: anything that leaves this function must be canonical (or flag the tile for the exact redo)
     if (wact) {
@@ -415,13 +449,19 @@ static const u64 *pass_table(zk_ctx *ctx, const PassParams &p, bool dit, bool st
     return t;
 }
 
-template <bool DIT, bool ROW, int W>
-static void launch_w(zk_ctx *ctx, const PassParams &p, const char *name) {
+template <bool DIT, bool ROW, int W, bool INV>
+static void launch_wi(zk_ctx *ctx, const PassParams &p, const char *name) {
     size_t n = (size_t)1 << p.k, blocks;
     if (ROW) { size_t rows = (n >> p.W) * (size_t)p.n_cols; blocks = (rows + ((size_t)1 << p.TL) - 1) >> p.TL; }
     else blocks = ((n >> p.W) >> p.TL) * (size_t)p.n_cols;
-    size_t shmem = (((size_t)1 << (p.W + p.TL)) + ((size_t)1 << p.W)) * sizeof(u64);
-    ZK_LAUNCH(ctx, name, (ntt_fast_kernel<DIT, ROW, W>), dim3((unsigned)blocks), dim3(512), shmem, p);
+    constexpr int P2 = (W - 4) < 4 ? (W - 4) : 4, P3 = W - 4 - P2;
+    const size_t row_stride = ((size_t)1 << W) + ((ROW && W >= 8) ? ((size_t)16 << P3) : 0);      // == RS in the kernel
+    size_t shmem = ((ROW ? (row_stride << p.TL) : ((size_t)1 << (p.W + p.TL))) + ((size_t)1 << p.W)) * sizeof(u64);
+    ZK_LAUNCH(ctx, name, (ntt_fast_kernel<DIT, ROW, W, INV>), dim3((unsigned)blocks), dim3(512), shmem, p);
+}
+template <bool DIT, bool ROW, int W>
+static void launch_w(zk_ctx *ctx, const PassParams &p, const char *name) {
+    if (p.inverse) launch_wi<DIT, ROW, W, true>(ctx, p, name); else launch_wi<DIT, ROW, W, false>(ctx, p, name);
 }
 template <bool DIT, bool ROW>
 static bool launch_dr(zk_ctx *ctx, const PassParams &p, const char *name) {

@@ -48,3 +48,6 @@ static inline void zk_fri_arities(const zk_stark_config &cfg, u32 degree_bits, u
     while (d > cfg.fri_final_poly_bits && d + cfg.rate_bits - cfg.fri_arity_bits >= cfg.cap_height) { out[k++] = cfg.fri_arity_bits; d -= cfg.fri_arity_bits; }
     *n_out = k;
 }
+
+// prover_quotient.hip: L_first | L_last (two columns of L = n << rate_bits) on the coset g*H_L, leaf order; cached per (log_n, rate_bits)
+int32_t zk_lagrange_table(zk_ctx *ctx, u32 log_n, u32 rate_bits, u64 **out);

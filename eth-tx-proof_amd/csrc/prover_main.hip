@@ -92,16 +92,17 @@ static inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
                                  uint64_t *proof_out, size_t cap_words, size_t *len_words);
 
-// Cold start: the first unit of a process is proved alone.  The HIP runtime loads this library's code objects lazily at the first
-// launch of each kernel and the constraint kernels are compiled and loaded (hiprtc, hipModuleLoadData) at first use; with several
-// contexts doing all of that at once from different threads, first proofs ended in sporadic GPU memory faults on this stack
-// (seen in bench.py with four streams; never once every thread had a proof behind it).  Later units run fully concurrently.
+// Round 1 serialised the first proof of a process behind a mutex ("cold start") after sporadic GPU memory faults in bench.py.  The
+// fault hunt of round 2 (tools/stress_faults.py: 8 streams x 100 full-size proofs x {build-time, hiprtc, interpreter} kernels x
+// {plain, fence allocator, a scratch-resident kernel between the real ones, mutex off}, each in a fresh process:
+// profiles/r02g_stress_faults.jsonl) ran 9600 proofs without a fault or a differing proof word, with the mutex off as well, so
+// the serialisation is off by default; ZK_COLD_MUTEX=1 brings it back.
 extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
                                    uint64_t *proof_out, size_t cap_words, size_t *len_words) {
     static std::atomic<bool> warm{false};
     static std::mutex cold_mu;
-    static const bool no_cold = getenv("ZK_NO_COLD_MUTEX") && atoi(getenv("ZK_NO_COLD_MUTEX"));     // stress runs: workaround off
-    if (no_cold || warm.load(std::memory_order_acquire)) return prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
+    static const bool cold = getenv("ZK_COLD_MUTEX") && atoi(getenv("ZK_COLD_MUTEX"));
+    if (!cold || warm.load(std::memory_order_acquire)) return prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
     std::lock_guard<std::mutex> lk(cold_mu);
     int32_t rc = prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
     if (rc == ZK_OK) warm.store(true, std::memory_order_release);

@@ -165,7 +165,7 @@ __global__ void canon_copy_kernel(const u64 *in, u64 *out, u32 n) {
 __global__ void set_indicator_kernel(u64 *ind, size_t n) { if (threadIdx.x == 0 && blockIdx.x == 0) { ind[0] = 1; ind[n + n - 1] = 1; } }
 
 // lagrange_first / lagrange_last = PolynomialValues::selector(n, idx).lde_onto_coset(rate_bits), leaf order; cached per size
-static int32_t lagrange_table(zk_ctx *ctx, u32 log_n, u32 rate_bits, u64 **out) {
+int32_t zk_lagrange_table(zk_ctx *ctx, u32 log_n, u32 rate_bits, u64 **out) {
     auto key = std::make_pair((int)log_n, (int)rate_bits);
     auto it = ctx->lagrange_tab.find(key);
     if (it != ctx->lagrange_tab.end()) { *out = it->second; return ZK_OK; }
@@ -202,7 +202,7 @@ int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &c
     p.trace_lde = trace->lde; p.aux_lde = aux ? aux->lde : nullptr;
     p.C = trace->n_cols; p.A = aux ? aux->n_cols : 0; p.lgL = lgL; p.nch = nch; p.rate_bits = rate_bits; p.L = L;
     u64 *lag = nullptr;
-    int32_t rc = lagrange_table(ctx, log_n, rate_bits, &lag);
+    int32_t rc = zk_lagrange_table(ctx, log_n, rate_bits, &lag);
     if (rc) return rc;
     p.lag = lag;
     TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);

@@ -311,10 +311,12 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
             std::vector<char> &code = *k.image;
             if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: hipModuleLoadData failed");
             if (hipModuleGetFunction(&k.fn, k.mod, "quotient_jit") != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: kernel not found in module");
-            // A generated kernel that spills to scratch is not used: with several streams in flight such kernels ended in GPU
-            // memory faults on this stack (seen with __launch_bounds__(256, 4), 264 B of scratch); the interpreter takes over.
+            // Round 1 refused generated kernels that spill to scratch (faults were seen with such kernels on several streams).  Round 2's
+            // fault hunt ran a scratch-resident kernel between the real kernels of 2400 proofs on 8 streams without a fault
+            // (profiles/r02g_stress_faults.jsonl), so spilling kernels are used; ZK_QUOTIENT_JIT_NO_SCRATCH=1 refuses them again.
+            static const bool no_scratch = getenv("ZK_QUOTIENT_JIT_NO_SCRATCH") && atoi(getenv("ZK_QUOTIENT_JIT_NO_SCRATCH"));
             int scratch = 0;
-            if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.fn) != hipSuccess || scratch > 0) k.fn = nullptr;
+            if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.fn) != hipSuccess || (no_scratch && scratch > 0)) k.fn = nullptr;
             if (k.fn) {
                 // settle the freshly loaded code object before it is used in earnest: drain the stream, run the kernel once
                 // with L = 0 (every thread returns at its first instruction) and wait for it

@@ -1,0 +1,119 @@
+"""Plonk-shaped circuits as plain data (include/zkgl.h: zk_plonk_circuit) and a synthetic family with satisfying witnesses.
+
+The reference proves its recursion circuits (shrink / root / aggregation / block: /root/reference/ops/src/lib.rs:52,72,95) with
+plonky2's CircuitConfig::standard_recursion_config(): 135 wires, 80 routed, quotient degree factor 8.  Those circuits' gate
+sets and witness generators live in crates that are absent from the reference tree, so -- like the tables' AIRs --
+a circuit here is data: constant/selector columns, the routed-wire permutation as sigma values, and a straight-line gate program.
+`synthetic_circuit` builds one with the recursion config's shape and a witness that satisfies it:
+  * copy constraints: routed columns 2j and 2j+1 are tied cell by cell (2-cycles), columns of every fourth pair additionally
+    tie row r to row r^1 (4-cycles), the rest of the permutation is the identity;
+  * gates (all filtered by a 0/1 selector column, so the degree goes up by one): multiply-add  c0*a*b + c1*c - d  on routed
+    wires with the result in an advice wire, and the degree-7 s-box  a^7 - e  (e an advice wire): degree 8 with the selector.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._abi import Air, HelperDesc, Instr, OP_ADD, OP_EMIT, OP_MUL, OP_SUB, OPND_CONST, OPND_LOCAL, OPND_REG, opnd, u32, u64
+from .air import AirProgram
+
+P = 0xFFFFFFFF00000001
+GEN = 14293326489335486720
+
+
+class PlonkCircuit(C.Structure):
+    """zk_plonk_circuit (include/zkgl.h)"""
+    _fields_ = [("degree_bits", u32), ("num_wires", u32), ("num_routed_wires", u32), ("num_constants", u32),
+                ("quotient_degree_factor", u32), ("reserved", u32), ("gates", C.c_void_p), ("constants", C.c_void_p),
+                ("sigmas", C.c_void_p)]
+
+
+class Circuit:
+    """Owns the arrays behind a zk_plonk_circuit; `.ref` is a pointer to the struct."""
+
+    def __init__(self, degree_bits, num_wires, num_routed, constants, sigmas, gates, qdf=8):
+        self.degree_bits, self.num_wires, self.num_routed, self.qdf = degree_bits, num_wires, num_routed, qdf
+        self.constants = np.ascontiguousarray(constants, dtype=np.uint64)
+        self.sigmas = np.ascontiguousarray(sigmas, dtype=np.uint64)
+        self.num_constants = self.constants.shape[0]
+        self.gates = gates
+        self.c = PlonkCircuit(degree_bits, num_wires, num_routed, self.num_constants, qdf, 0, C.cast(gates.ref, C.c_void_p),
+                              self.constants.ctypes.data, self.sigmas.ctypes.data)
+        self.ref = C.pointer(self.c)
+
+
+def _pow(b, e):
+    return pow(int(b), int(e), P)
+
+
+def _root(k):
+    return _pow(7277203076849721926, 1 << (32 - k))
+
+
+def synthetic_circuit(degree_bits=12, num_wires=135, num_routed=80, n_muladd=16, n_sbox=8, seed=1):
+    """Returns (Circuit, wires) with wires a (num_wires, n) uint64 witness satisfying gates and copy constraints."""
+    n = 1 << degree_bits
+    rng = np.random.default_rng(seed)
+
+    def rand(shape):
+        a = rng.integers(0, 1 << 63, size=shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=shape, dtype=np.uint64)
+        return np.where(a >= np.uint64(P), a - np.uint64(P), a)
+    assert num_routed % 8 == 0 and num_routed <= num_wires and num_wires - num_routed >= n_muladd + n_sbox
+    # ---- permutation: cell (j, r) -> (j2, r2); sigma_j(w^r) = k_{j2} * w^{r2}, k_j = g^j
+    col = np.tile(np.arange(num_routed, dtype=np.int64)[:, None], (1, n))
+    row = np.tile(np.arange(n, dtype=np.int64)[None, :], (num_routed, 1))
+    tcol, trow = col.copy(), row.copy()
+    for j in range(0, num_routed, 2):
+        if (j // 2) % 4 == 0:      # 4-cycles: (j, r) -> (j+1, r) -> (j, r^1) -> (j+1, r^1) -> (j, r)
+            tcol[j], trow[j] = j + 1, row[j]
+            tcol[j + 1], trow[j + 1] = j, row[j + 1] ^ 1
+        elif (j // 2) % 4 in (1, 2):   # 2-cycles within the row
+            tcol[j], tcol[j + 1] = j + 1, j
+        # else: identity
+    ks = [_pow(GEN, j) for j in range(num_routed)]
+    w = _root(degree_bits)
+    wpow = np.empty(n, dtype=object)
+    x = 1
+    for r in range(n):
+        wpow[r] = x
+        x = x * w % P
+    sig = np.empty((num_routed, n), dtype=np.uint64)
+    for j in range(num_routed):
+        kk = np.array([ks[c] for c in tcol[j]], dtype=object)
+        sig[j] = np.array([(int(a) * int(b)) % P for a, b in zip(kk, wpow[trow[j]])], dtype=np.uint64)
+    # ---- witness: routed wires constant on the cycles
+    wires = rand((num_wires, n))
+    for j in range(0, num_routed, 2):
+        kind = (j // 2) % 4
+        if kind == 0:
+            base = wires[j].copy()
+            base[1::2] = base[0::2]
+            wires[j] = base; wires[j + 1] = base
+        elif kind in (1, 2):
+            wires[j + 1] = wires[j]
+    # ---- constants: c0, c1 (arbitrary), selector (0/1)
+    consts = rand((3, n))
+    consts[2] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    W = num_wires
+    Lc = lambda i: opnd(OPND_LOCAL, i)
+    R = lambda i: opnd(OPND_REG, i)
+    ins = []
+    adv = num_routed
+
+    def obj(a):
+        return a.astype(object)
+    for m in range(n_muladd):
+        a, b, c_ = (5 * m) % num_routed, (5 * m + 2) % num_routed, (5 * m + 3) % num_routed
+        d = adv; adv += 1
+        wires[d] = np.array([(int(c0) * int(x) % P * int(y) + int(c1) * int(z)) % P
+                             for c0, c1, x, y, z in zip(consts[0], consts[1], wires[a], wires[b], wires[c_])], dtype=np.uint64)
+        ins += [(OP_MUL, 0, Lc(a), Lc(b)), (OP_MUL, 0, R(0), Lc(W + 0)), (OP_MUL, 1, Lc(c_), Lc(W + 1)), (OP_ADD, 0, R(0), R(1)),
+                (OP_SUB, 0, R(0), Lc(d)), (OP_MUL, 0, R(0), Lc(W + 2)), (OP_EMIT, 0, R(0), 0)]
+    for m in range(n_sbox):
+        a = (7 * m + 1) % num_routed
+        e = adv; adv += 1
+        wires[e] = np.array([pow(int(x), 7, P) for x in wires[a]], dtype=np.uint64)
+        ins += [(OP_MUL, 0, Lc(a), Lc(a)), (OP_MUL, 1, R(0), Lc(a)), (OP_MUL, 0, R(0), R(0)), (OP_MUL, 0, R(0), R(1)),   # a^2, a^3, a^4, a^7
+                (OP_SUB, 0, R(0), Lc(e)), (OP_MUL, 0, R(0), Lc(W + 2)), (OP_EMIT, 0, R(0), 0)]
+    gates = AirProgram(W + 3, 0, [], [1], ins, 2)
+    return Circuit(degree_bits, num_wires, num_routed, consts, sig, gates), np.ascontiguousarray(wires, dtype=np.uint64)

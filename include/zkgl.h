@@ -293,6 +293,47 @@ int32_t zk_fri_prove_instance(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t 
                               uint32_t n_batches, const zk_fri_batch *batches, zk_challenger *ch, uint64_t *fri_proof_out,
                               size_t cap_words, size_t *len_words);
 
+/* ------------------------------------------------------------------ Plonk-shaped proof
+ * What generate_txn_proof / generate_agg_proof / generate_block_proof (/root/reference/ops/src/lib.rs:52,72,95) spend their time in
+ * after the STARK proofs: plonky2::plonk::prover::prove over a circuit built with CircuitConfig::standard_recursion_config()
+ * (135 wires, 80 routed, quotient degree factor 8, FRI rate_bits 3 / cap 4 / 28 queries).  The real recursion circuits (gate set,
+ * recursive verifier gadgets, witness generators) live in crates that are absent from the reference tree, so -- as for the tables'
+ * AIRs -- a circuit is plain data here: wire count, routed-wire permutation (sigma values), constant / selector columns and a
+ * straight-line gate-constraint program.  The prover work is upstream's, step by step (plonk/prover.rs prove_with_partition_witness):
+ *   wires commit -> observe circuit digest, public-input hash, wires cap -> betas, gammas -> partial products and Z of the
+ *   routed-wire permutation (chunks of quotient_degree_factor) -> commit [Z.., partial products..] -> alphas -> vanishing polynomial
+ *   on the 8n coset = [L_0 (Z - 1) .., partial-product checks .., gate constraints ..] reduced with powers of alpha, / Z_H ->
+ *   quotient chunks commit -> zeta -> OpeningSet -> PolynomialBatch::prove_openings over the four oracles
+ *   (constants_sigmas, wires, zs_partial_products, quotient; batches at zeta and at g*zeta for the Zs).
+ * Gate program: zk_air with n_trace_cols = num_wires + num_constants (LOCAL index i < num_wires = wire i, else constant column
+ * i - num_wires), ops ADD / SUB / MUL / EMIT only, no NEXT / PUBLIC / CHALLENGE operands, n_helpers = 0.
+ *
+ * Proof words: "ZKGLPLK1", degree_bits, num_wires, num_routed, num_constants, wires_cap, zs_partial_products_cap, quotient_cap,
+ *   openings: constants[NC x2] sigmas[R x2] wires[W x2] zs[nch x2] zs_next[nch x2] partial_products[nch*npp x2]
+ *             quotient[nch*qdf x2],  then the FriProof words in the layout of zk_fri_prove_instance. */
+typedef struct {
+    uint32_t degree_bits;             /* n = 2^degree_bits rows */
+    uint32_t num_wires;               /* 135 */
+    uint32_t num_routed_wires;        /* 80 */
+    uint32_t num_constants;           /* constant + selector columns */
+    uint32_t quotient_degree_factor;  /* 8: chunk size of the partial products, number of quotient chunks per challenge */
+    uint32_t reserved;
+    const zk_air *gates;              /* the gate-constraint program */
+    const uint64_t *constants;        /* num_constants x n, column-major: values on the subgroup H */
+    const uint64_t *sigmas;           /* num_routed_wires x n: sigma_j(w^r) = k_j' * w^r' for the cell (j', r') that (j, r) maps to, k_j = g^j */
+} zk_plonk_circuit;
+typedef struct zk_plonk_state zk_plonk_state;   /* prover data of one circuit: constants_sigmas commitment, digest; device resident */
+/* CircuitBuilder::build's prover-side part: commit constants | sigmas (rate_bits, cap_height of cfg), derive the circuit digest
+ * = hash_no_pad(cap | 0^4 | degree_bits).  cfg: zk_stark_config with the recursion parameters (rate_bits 3, 28 query rounds ..). */
+int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const zk_plonk_circuit *circuit, zk_plonk_state **out);
+int32_t zk_plonk_state_free(zk_plonk_state *st);
+int32_t zk_plonk_circuit_digest(zk_plonk_state *st, uint64_t digest_out[4]);
+size_t zk_plonk_proof_size_words(const zk_stark_config *cfg, const zk_plonk_circuit *circuit);
+/* wires: num_wires x n column-major witness (host, or device when wires_on_device != 0); public_inputs: hashed into the transcript */
+int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfg, zk_plonk_state *st, const uint64_t *wires, uint32_t wires_on_device,
+                       const uint64_t *public_inputs, uint32_t n_public_inputs, uint64_t *proof_out, size_t proof_cap_words,
+                       size_t *proof_len_words);
+
 /* Synthetic satisfying witness for eth_tx_proof_amd.air.cpu_like_air, generated in HBM;
  * public_inputs_out (host, 3 words, may be NULL) = first-row a0, b0 and last-row a0. */
 int32_t zk_synth_trace_dev(zk_ctx *ctx, uint32_t n_cols, uint32_t log_n, uint64_t seed, uint64_t *d_trace,

@@ -119,6 +119,17 @@ int32_t orc_fri_prove_instance(const zk_stark_config *cfg, uint32_t n_oracles, c
                                const zk_fri_batch *batches, orc_challenger *ch, uint64_t *out, size_t cap_words, size_t *len_words);
 size_t orc_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const orc_table *tables);
 
+/* plonky2::plonk::{prover, verifier} over a circuit given as plain data (zk_plonk_circuit, include/zkgl.h); plonk.c */
+typedef struct orc_plonk_state orc_plonk_state;
+orc_plonk_state *orc_plonk_setup(const zk_stark_config *cfg, const zk_plonk_circuit *circuit);
+void orc_plonk_state_free(orc_plonk_state *st);
+void orc_plonk_digest(const orc_plonk_state *st, uint64_t out[4]);
+size_t orc_plonk_proof_size_words(const zk_stark_config *cfg, const zk_plonk_circuit *circuit);
+int32_t orc_prove_plonk(const zk_stark_config *cfg, orc_plonk_state *st, const uint64_t *wires, const uint64_t *public_inputs, uint32_t n_public_inputs,
+                        uint64_t *proof_out, size_t cap_words, size_t *len_words);
+int32_t orc_verify_plonk(const zk_stark_config *cfg, const orc_plonk_state *st, const uint64_t *public_inputs, uint32_t n_public_inputs,
+                         const uint64_t *proof, size_t len_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -291,3 +291,48 @@ def fri_prove_instance(cfg, oracles, batches, challenger, cap_words=1 << 23):
     rc = lib().orc_fri_prove_instance(C.byref(cfg), C.c_uint32(len(oracles)), hs, C.c_uint32(len(batches)), arr,
                                       C.byref(challenger.s), _p(out), C.c_size_t(cap_words), C.byref(ln))
     return rc, out[:ln.value]
+
+
+# ---- Plonk-shaped proofs (oracle/plonk.c)
+class PlonkState:
+    """orc_plonk_state: constants_sigmas commitment + digest of one circuit"""
+
+    def __init__(self, cfg, circuit):
+        L = lib()
+        L.orc_plonk_setup.restype = C.c_void_p
+        self.circuit, self.cfg = circuit, cfg
+        self.h = L.orc_plonk_setup(C.byref(cfg), circuit.ref)
+        if not self.h:
+            raise ValueError("orc_plonk_setup: malformed circuit")
+
+    def digest(self):
+        out = np.empty(4, dtype=np.uint64)
+        lib().orc_plonk_digest(C.c_void_p(self.h), _p(out))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_plonk_state_free(C.c_void_p(self.h))
+        except Exception:
+            pass
+
+
+def plonk_proof_size_words(cfg, circuit):
+    f = lib().orc_plonk_proof_size_words
+    f.restype = C.c_size_t
+    return f(C.byref(cfg), circuit.ref)
+
+
+def prove_plonk(state, wires, public_inputs):
+    wires, pub = u64(wires), u64(public_inputs)
+    n = plonk_proof_size_words(state.cfg, state.circuit)
+    out = np.empty(n, dtype=np.uint64)
+    ln = C.c_size_t(0)
+    rc = lib().orc_prove_plonk(C.byref(state.cfg), C.c_void_p(state.h), _p(wires), _p(pub), C.c_uint32(pub.size), _p(out), C.c_size_t(n), C.byref(ln))
+    return rc, out[:ln.value]
+
+
+def verify_plonk(state, public_inputs, proof):
+    pub, proof = u64(public_inputs), u64(proof)
+    return lib().orc_verify_plonk(C.byref(state.cfg), C.c_void_p(state.h), _p(pub), C.c_uint32(pub.size), _p(proof), C.c_size_t(proof.size))
