@@ -445,3 +445,53 @@ def prover_state_stats():
     a, b = C.c_uint64(0), C.c_uint64(0)
     lib().zk_prover_state_stats(C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+# ---- Plonk-shaped proofs (zk_plonk_setup / zk_prove_plonk)
+class PlonkState:
+    """zk_plonk_state: the prover data of one circuit (constants_sigmas commitment, digest), device resident."""
+
+    def __init__(self, ctx, cfg, circuit):
+        self.ctx, self.cfg, self.circuit = ctx, cfg, circuit
+        self.h = C.c_void_p()
+        ctx._chk(lib().zk_plonk_setup(ctx.h, C.byref(cfg), circuit.ref, C.byref(self.h)), "zk_plonk_setup")
+
+    def digest(self):
+        out = np.empty(4, dtype=np.uint64)
+        self.ctx._chk(lib().zk_plonk_circuit_digest(self.h, _p(out)), "zk_plonk_circuit_digest")
+        return out
+
+    def free(self):
+        if self.h:
+            lib().zk_plonk_state_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+def plonk_proof_size_words(cfg, circuit):
+    f = lib().zk_plonk_proof_size_words
+    f.restype = C.c_size_t
+    return f(C.byref(cfg), circuit.ref)
+
+
+def prove_plonk(state, wires, public_inputs):
+    """zk_prove_plonk: wires = (num_wires, n) uint64 host array or an int device pointer (canonical values)."""
+    pub = _u64(public_inputs)
+    n = plonk_proof_size_words(state.cfg, state.circuit)
+    out = np.empty(n, dtype=np.uint64)
+    ln = C.c_size_t(0)
+    if isinstance(wires, (int, np.integer)):
+        wp, on_dev, keep = C.c_void_p(int(wires)), 1, None
+    else:
+        keep = wires if (isinstance(wires, np.ndarray) and wires.dtype == np.uint64 and wires.flags.c_contiguous) else _u64(wires)
+        wp, on_dev = keep.ctypes.data_as(C.c_void_p), 0
+    rc = lib().zk_prove_plonk(state.ctx.h, C.byref(state.cfg), state.h, wp, C.c_uint32(on_dev), _p(pub), C.c_uint32(pub.size), _p(out),
+                              C.c_size_t(n), C.byref(ln))
+    state.ctx._chk(rc, "zk_prove_plonk")
+    return out[:ln.value]

@@ -1,0 +1,77 @@
+"""zk_prove_plonk on the GPU against oracle/plonk.c: same circuit, same witness, same public inputs -> the same proof words, bit
+for bit, and the oracle's verifier accepts them (the recursion half of generate_txn_proof / generate_agg_proof /
+generate_block_proof, /root/reference/ops/src/lib.rs:52,72,95, on a synthetic circuit with the recursion config's shape)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+    import eth_tx_proof_amd as E
+    return E.standard_recursion_config()
+
+
+@pytest.mark.parametrize("degree_bits,seed", [(6, 1), (9, 2), (12, 3), (13, 4)])
+def test_plonk_proof_bit_exact_vs_oracle(ctx, zk, orc, degree_bits, seed):
+    from eth_tx_proof_amd import plonk
+    cfg = _cfg()
+    circ, wires = plonk.synthetic_circuit(degree_bits=degree_bits, seed=seed)
+    pub = np.array([degree_bits, seed, 99], dtype=np.uint64)
+    ost = orc.PlonkState(cfg, circ)
+    st = zk.PlonkState(ctx, cfg, circ)
+    try:
+        assert (st.digest() == ost.digest()).all()
+        proof = zk.prove_plonk(st, wires, pub)
+        rc, ref = orc.prove_plonk(ost, wires, pub)
+        assert rc == 0 and proof.size == ref.size == zk.plonk_proof_size_words(cfg, circ)
+        if not (proof == ref).all():
+            bad = np.nonzero(proof != ref)[0]
+            pytest.fail("first differing word %d of %d (%d differ)" % (bad[0], proof.size, bad.size))
+        assert orc.verify_plonk(ost, pub, proof) == 0
+        assert (zk.prove_plonk(st, wires, pub) == proof).all()
+    finally:
+        st.free()
+
+
+def test_plonk_2_14_rows_recursion_shape_verifies_and_rejects(ctx, zk, orc):
+    """2^14 rows x 135 wires (about the size of the reference's root circuit): device-resident witness, verifier accepts, a flipped
+    word and a witness that breaks a copy constraint are rejected."""
+    from eth_tx_proof_amd import plonk
+    cfg = _cfg()
+    circ, wires = plonk.synthetic_circuit(degree_bits=14, seed=14)
+    pub = np.arange(4, dtype=np.uint64)
+    ost = orc.PlonkState(cfg, circ)
+    st = zk.PlonkState(ctx, cfg, circ)
+    try:
+        d = ctx.dev_alloc(wires.nbytes)
+        ctx.upload(d, wires)
+        proof = zk.prove_plonk(st, d, pub).copy()
+        assert orc.verify_plonk(ost, pub, proof) == 0
+        assert (zk.prove_plonk(st, wires, pub) == proof).all()          # host-resident witness: same proof
+        bad = proof.copy(); bad[proof.size // 2] ^= np.uint64(1)
+        assert orc.verify_plonk(ost, pub, bad) != 0
+        w = wires.copy(); w[8, 77] ^= np.uint64(1)
+        assert orc.verify_plonk(ost, pub, zk.prove_plonk(st, w, pub)) != 0
+        ctx.dev_free(d)
+    finally:
+        st.free()
+
+
+def test_plonk_error_paths(ctx, zk):
+    from eth_tx_proof_amd import plonk
+    import eth_tx_proof_amd as E
+    cfg = _cfg()
+    circ, wires = plonk.synthetic_circuit(degree_bits=5, seed=1)
+    circ.c.quotient_degree_factor = 4
+    with pytest.raises(zk.ZkError) as e:
+        zk.PlonkState(ctx, cfg, circ)
+    assert e.value.code == -1
+    circ.c.quotient_degree_factor = 8
+    st = zk.PlonkState(ctx, cfg, circ)
+    other = E.standard_fast_config()
+    st.cfg = other                                   # proving with another config than the one of the setup is refused
+    with pytest.raises(zk.ZkError):
+        zk.prove_plonk(st, wires, np.zeros(1, dtype=np.uint64))
+    st.cfg = cfg
+    st.free()
