@@ -93,11 +93,13 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     constexpr bool SWZ = ROW && W >= 8;
     constexpr int RS = (1 << W) + (SWZ ? (16 << P3) : 0);         // LDS row stride of a ROW tile, in elements
     extern __shared__ u64 sh[];
-    const int S = p.S, TL = p.TL;
+    // the tile always holds 2^13 elements (T = 2^(13-W) rows or adjacent positions): with the tile shape a compile-time constant
+    // every LDS index of an exchange is the thread's base plus an immediate offset (the launcher routes other shapes elsewhere)
+    constexpr int TL = 13 - W;
+    const int S = p.S;
     const u32 T = 1u << TL, tid = threadIdx.x;
-    const u32 nact = 1u << (W + TL - 4);
-    const bool act = tid < nact;
-    const bool wact = (u32)__builtin_amdgcn_readfirstlane((int)tid) < nact;     // wave-uniform: this wave holds live lanes
+    constexpr u32 nact = 512;
+    constexpr bool act = true, wact = true;
     const size_t n = (size_t)1 << p.k;
     const u64 *__restrict__ RW = p.tw_full;
 
@@ -477,9 +479,11 @@ static bool launch_dr(zk_ctx *ctx, const PassParams &p, const char *name) {
     }
 }
 bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, const char *name) {
-    if (p0.W < 4 || p0.W > 10 || p0.W + p0.TL > 13 || !p0.tw_full || p0.k > 30) return false;
+    if (p0.W < 4 || p0.W > 10 || !p0.tw_full || p0.k > 30) return false;
+    if (!row && p0.S < 13 - p0.W) return false;            // a TILE pass needs 2^(13-W) adjacent positions: smaller transforms take the LDS radix-2 kernel
     if (((((size_t)1 << p0.k) >> p0.W) * (size_t)p0.n_cols + 64) >> 32) return false;      // the kernel numbers rows in 32 bits
     PassParams p = p0;
+    p.TL = 13 - p.W;                                        // fixed tile shape (ROW tiles past the last row are skipped inside the kernel)
     p.force_redo = (int)ctx->force_redo;
     bool need_load = p.preA || (dit && p.S > 0);
     bool need_store = !p.permute_out && ((!dit && p.S > 0) || p.postA || p.post_const);

@@ -9,8 +9,21 @@
 #include <string.h>
 #include "zk_internal.h"
 #include "prover.h"
+#include "poseidon.cuh"
 
 #define PLK_MAX_CHUNKS 16
+
+// PoseidonHash::hash_no_pad of a short vector (public inputs, digest inputs): always the sponge, never hash_or_noop's copy branch
+__global__ void plonk_hash_no_pad_kernel(const u64 *in, u32 n, u64 *out) {
+    if (threadIdx.x || blockIdx.x) return;
+    u64 s[12];
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    for (u32 c = 0; c < n; c += 8) {
+        for (u32 i = 0; i < 8 && c + i < n; i++) s[i] = gl_canon(in[c + i]);
+        psd::permute(s);
+    }
+    for (int i = 0; i < 4; i++) out[i] = s[i];
+}
 
 struct zk_plonk_state {
     zk_ctx *ctx;
@@ -284,7 +297,7 @@ extern "C" int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const
             u64 tail[5] = {0, 0, 0, 0, c->degree_bits};
             ZK_LAUNCH(ctx, "plonk_copy", plonk_copy_kernel, g1(capw), dim3(256), 0, st->cs->cap(), d_in, capw);
             rc = zk_dev_upload(ctx, d_in + capw, tail, sizeof tail);
-            if (rc == ZK_OK) rc = zk_hash_leaves_rowmajor(ctx, d_in, capw + 5, 1, st->d_digest);
+            if (rc == ZK_OK) ZK_LAUNCH(ctx, "plonk_hash_no_pad", plonk_hash_no_pad_kernel, dim3(1), dim3(1), 0, (const u64 *)d_in, capw + 5, st->d_digest);
             if (rc == ZK_OK) rc = zk_dev_download(ctx, st->digest, st->d_digest, 4 * sizeof(u64));
         }
     }
@@ -344,7 +357,7 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
         std::vector<u64> pc(public_inputs, public_inputs + n_pub);
         for (auto &v : pc) v = gl_canon(v);
         if ((rc = ctx->upload_small(d_pub, pc.data(), pc.size() * sizeof(u64))) != ZK_OK) return rc;
-        if ((rc = zk_hash_leaves_rowmajor(ctx, d_pub, n_pub, 1, d_pih)) != ZK_OK) return rc;
+        ZK_LAUNCH(ctx, "plonk_hash_no_pad", plonk_hash_no_pad_kernel, dim3(1), dim3(1), 0, (const u64 *)d_pub, n_pub, d_pih);
     } else hipMemsetAsync(d_pih, 0, 4 * sizeof(u64), ctx->stream);
 
     // ---- wires commitment
