@@ -131,9 +131,16 @@ int32_t zk_ctx::upload_large(void *d_dst, const void *src, size_t bytes, hipStre
     }
     return ZK_OK;
 }
-void zk_ctx::wait_pending_uploads() {
-    for (hipEvent_t e : pending_uploads) { hipStreamWaitEvent(stream, e, 0); event_pool.push_back(e); }
-    pending_uploads.clear();
+void zk_ctx::wait_upload(const void *d_ptr) {
+    // only the prefetch that fills THIS buffer: the next unit's upload, already under way on the copy stream, must not hold the
+    // current unit's proof back
+    for (size_t i = 0; i < pending_uploads.size();) {
+        if (pending_uploads[i].first == d_ptr) {
+            hipStreamWaitEvent(stream, pending_uploads[i].second, 0);
+            event_pool.push_back(pending_uploads[i].second);
+            pending_uploads.erase(pending_uploads.begin() + i);
+        } else i++;
+    }
 }
 
 void zk_ctx::release(void *p) {
@@ -219,7 +226,7 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     if (c->h_out) hipHostFree(c->h_out);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 3; i++) if (c->part_stream[i]) { hipStreamSynchronize(c->part_stream[i]); hipStreamDestroy(c->part_stream[i]); }
-    for (hipEvent_t e : c->pending_uploads) hipEventDestroy(e);
+    for (auto &pe : c->pending_uploads) hipEventDestroy(pe.second);
     for (int i = 0; i < 2; i++) { if (c->h_chunk[i]) hipHostFree(c->h_chunk[i]); if (c->chunk_free[i]) hipEventDestroy(c->chunk_free[i]); }
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -265,6 +272,7 @@ int32_t zk_dev_alloc(zk_ctx *c, size_t bytes, void **d_ptr) {
 }
 int32_t zk_dev_free(zk_ctx *c, void *d_ptr) {
     if (!c) return ZK_ERR_INVALID_ARG;
+    c->wait_upload(d_ptr);                      // a prefetch into this buffer must land before the block can be reused
     c->release(d_ptr);
     return ZK_OK;
 }
@@ -297,7 +305,7 @@ int32_t zk_trace_upload_async(zk_ctx *c, const uint64_t *trace, size_t n_words, 
     if (rc == ZK_OK && hipEventRecord(done, c->copy_stream) != hipSuccess) rc = c->fail(ZK_ERR_HIP, "upload_async: event");
     if (before) c->event_pool.push_back(before);
     if (rc != ZK_OK) { if (done) c->event_pool.push_back(done); hipStreamSynchronize(c->copy_stream); c->release(d); return rc; }
-    c->pending_uploads.push_back(done);
+    c->pending_uploads.emplace_back(d, done);
     *d_ptr = (uint64_t *)d;
     return ZK_OK;
 }

@@ -85,7 +85,10 @@ __device__ __forceinline__ void radix_net(G &g, u64 (&x)[16], const int g0, cons
 }
 
 template <bool DIT, bool ROW, int W, bool INV>
-__global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
+// Two 512-thread workgroups per CU (64-78 KiB of LDS each) need <= 128 VGPRs: with the tile shape a constant hipcc hoists every
+// address of the pass and asks for ~140; bounded to 128 it spills 10-28 of them to scratch and is still the fastest variant measured
+// (from_values NTT at 2^20 x 93: 2.95 ms; unbounded 140 VGPRs: 3.98 ms; run-time tile shape, 84 VGPRs, +25 instructions: 3.3 ms).
+__global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
     constexpr int P2 = (W - 4) < 4 ? (W - 4) : 4;
     constexpr int P3 = W - 4 - P2;
     constexpr int R = 1 << (W - 4);
@@ -115,9 +118,6 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
         else { col = blockIdx.x / tiles_per_col; rem = blockIdx.x % tiles_per_col; }
         base = ((rem / tiles_per_block) << (W + S)) + ((rem % tiles_per_block) << TL);
     }
-    u64 tw16[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) tw16[j] = RW[j << (W - 4)];
     // the 2^W digit roots go to LDS behind the tile: the inter-phase twiddles are per-lane gathers, and an LDS gather costs a
     // fraction of an L1-hit global load's latency
     u64 *shRW = sh + (ROW ? ((size_t)RS << TL) : ((size_t)1 << (W + TL)));
@@ -182,6 +182,11 @@ __global__ __launch_bounds__(512) void ntt_fast_kernel(PassParams p) {
     };
 
     auto compute = [&](auto &fx) {
+    // the in-network twiddles as table values: only the exact arithmetic reads them (the fast arithmetic shifts), so they are
+    // loaded here rather than held in 16 registers through the fast path
+    u64 tw16[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) tw16[j] = std::remove_reference_t<decltype(fx)>::exact ? RW[j << (W - 4)] : 0;
     // ---------------------------------------------------------------- load (+ input scale, + DIT pass pre-twiddle)
     // Loads (and the factor loads) are guarded per lane and issued back to back; the products run after them in wave-uniform
     // control flow, because the sticky word of glx<false> is a scalar: inactive lanes multiply 0 by 1.

@@ -78,13 +78,13 @@ struct TxProof {
 };
 struct AggProof {
     AggregatableProof combine(const AggregatableProof &, const AggregatableProof &) {
-        throw FatalError("generate_agg_proof: recursive aggregation is outside the built hot path (SURVEY.md 8f-2)");
+        throw FatalError("generate_agg_proof: the aggregation circuit is not available (SURVEY.md 8f-2, A10); zk_prove_plonk proves circuits given as data");
     }
     AggregatableProof empty() { throw std::logic_error("empty agg proof"); }   // lib.rs:78-81 unimplemented!
 };
 struct BlockProof {
     AggregatableProof execute(const AggregatableProof &) {
-        throw FatalError("generate_block_proof: block circuit is outside the built hot path (SURVEY.md 8f-2)");
+        throw FatalError("generate_block_proof: the block circuit is not available (SURVEY.md 8f-2, A10); zk_prove_plonk proves circuits given as data");
     }
 };
 

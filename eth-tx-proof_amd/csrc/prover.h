@@ -51,3 +51,6 @@ static inline void zk_fri_arities(const zk_stark_config &cfg, u32 degree_bits, u
 
 // prover_quotient.hip: L_first | L_last (two columns of L = n << rate_bits) on the coset g*H_L, leaf order; cached per (log_n, rate_bits)
 int32_t zk_lagrange_table(zk_ctx *ctx, u32 log_n, u32 rate_bits, u64 **out);
+// prover_fri.hip: the combination half of prove_openings (alpha on the device) -> final values F (re | im columns of L, leaf order)
+int32_t zk_fri_final_values_dev(zk_ctx *ctx, const zk_stark_config &cfg, const u64 *d_alpha, const zk_batch *const *oracles, u32 n_oracles,
+                                const FriBatchDesc *batches, u32 nb, u64 *F);

@@ -458,8 +458,10 @@ __global__ __launch_bounds__(256) void fri_quotient_gen_kernel(QuotGenParams p) 
     p.F[s] = F.a; p.F[p.L + s] = F.b;
 }
 
-int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *const *oracles, u32 n_oracles,
-                                  const FriBatchDesc *batches, u32 nb, u64 *d_proof, const FriLayout &lay) {
+// PolynomialBatch::prove_openings up to (not including) fri_proof: the final values F (re | im columns of L, leaf order) of
+//   sum_b alpha^(..) (P_b - P_b(z_b)) / (X - z_b),  P_b = sum_j alpha^j f_j over the batch's polynomials; alpha at d_alpha (device)
+int32_t zk_fri_final_values_dev(zk_ctx *ctx, const zk_stark_config &cfg, const u64 *d_alpha, const zk_batch *const *oracles, u32 n_oracles,
+                                const FriBatchDesc *batches, u32 nb, u64 *F) {
     const u32 log_n = oracles[0]->log_n, rate_bits = cfg.rate_bits, lgL = log_n + rate_bits;
     const size_t n = (size_t)1 << log_n, L = n << rate_bits;
     if (nb == 0 || nb > FRI_MAX_BATCHES || n_oracles == 0 || n_oracles > 8) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: 1..4 batches, 1..8 oracles");
@@ -488,19 +490,16 @@ int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevCh
             return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: oracles must share log_n and the config's rate_bits / cap_height");
     int32_t rc = ZK_OK;
     ZkOwned own(ctx);
-    u64 *d_alpha = (u64 *)own.get(2 * sizeof(u64));
     u64 *d_apow = (u64 *)own.get((size_t)(gp.cnt + FRI_MAX_BATCHES) * 2 * sizeof(u64));
     u64 *d_pts = (u64 *)own.get(2 * FRI_MAX_BATCHES * sizeof(u64)), *d_ev = (u64 *)own.get(4 * FRI_MAX_BATCHES * sizeof(u64));
     u64 *d_y = (u64 *)own.get(2 * FRI_MAX_BATCHES * sizeof(u64));
     const u64 **d_cols = (const u64 **)own.get(cols.size() * sizeof(u64 *));
     u64 *P = (u64 *)own.get(2 * nb * n * sizeof(u64)), *Pval = (u64 *)own.get(2 * nb * L * sizeof(u64)), *tmp = (u64 *)own.get(2 * nb * n * sizeof(u64));
-    u64 *F = (u64 *)own.get(2 * L * sizeof(u64));
-    if (!d_alpha || !d_apow || !d_pts || !d_ev || !d_y || !d_cols || !P || !Pval || !tmp || !F) return ctx->fail(ZK_ERR_OOM, "fri instance: out of device memory");
+    if (!d_apow || !d_pts || !d_ev || !d_y || !d_cols || !P || !Pval || !tmp) return ctx->fail(ZK_ERR_OOM, "fri instance: out of device memory");
     rc = zk_dev_upload(ctx, d_pts, hpts, sizeof hpts);
     if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_cols, cols.data(), cols.size() * sizeof(u64 *));
     if (rc) return rc;
-    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_alpha; a.op[0].n = 2; zk_transcript_run(ctx, ch, a); }
-    ZK_LAUNCH(ctx, "fri_alpha_pows", alpha_pows_gen_kernel, g1(gp.cnt + FRI_MAX_BATCHES), dim3(256), 0, (const u64 *)d_alpha, gp, d_apow);
+    ZK_LAUNCH(ctx, "fri_alpha_pows", alpha_pows_gen_kernel, g1(gp.cnt + FRI_MAX_BATCHES), dim3(256), 0, d_alpha, gp, d_apow);
     cp.cols = d_cols; cp.n = n; cp.apow = d_apow; cp.P = P;
     ZK_LAUNCH(ctx, "fri_combine", fri_combine_gen_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, cp);
     // P_b(z_b): what divide_by_linear drops as the remainder
@@ -518,7 +517,206 @@ int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevCh
     TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
     qp.xA = xs.A; qp.xB = xs.B; qp.pts = d_pts; qp.y = d_y; qp.shifts = d_apow + 2 * gp.cnt; qp.F = F;
     ZK_LAUNCH(ctx, "fri_quotient", fri_quotient_gen_kernel, g1(L), dim3(256), 0, qp);
-    own.drop(d_alpha); own.drop(d_apow); own.drop(d_pts); own.drop(d_ev); own.drop(d_y); own.drop((void *)d_cols);
-    own.drop(P); own.drop(Pval); own.drop(tmp);
+    return ZK_OK;
+}
+
+int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *const *oracles, u32 n_oracles,
+                                  const FriBatchDesc *batches, u32 nb, u64 *d_proof, const FriLayout &lay) {
+    if (n_oracles == 0 || n_oracles > 8) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: 1..8 oracles");
+    const u32 log_n = oracles[0]->log_n;
+    const size_t L = (size_t)1 << (log_n + cfg.rate_bits);
+    ZkOwned own(ctx);
+    u64 *d_alpha = (u64 *)own.get(2 * sizeof(u64)), *F = (u64 *)own.get(2 * L * sizeof(u64));
+    if (!d_alpha || !F) return ctx->fail(ZK_ERR_OOM, "fri instance: out of device memory");
+    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_alpha; a.op[0].n = 2; zk_transcript_run(ctx, ch, a); }
+    int32_t rc = zk_fri_final_values_dev(ctx, cfg, d_alpha, oracles, n_oracles, batches, nb, F);
+    if (rc) return rc;
     return zk_fri_proof_dev(ctx, cfg, ch, log_n, F, oracles, n_oracles, d_proof, lay);
 }
+
+// ------------------------------------------------------------------ finer-grained FRI entry points
+// The same steps as zk_fri_prove_instance_dev, one upstream item per call, synchronous, for callers that replace plonky2's FRI
+// prover piece by piece: zk_fri_combine (the batch combination of PolynomialBatch::prove_openings), zk_fri_commit_begin /
+// zk_fri_fold_commit_layer / zk_fri_commit_finish (fri_committed_trees, one reduction layer per call), zk_fri_query
+// (fri_prover_query_round).  The proof of work between finish and the queries is zk_pow_grind.
+__global__ void deinterleave_kernel(const u64 *in, size_t n, u64 *re, u64 *im) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { re[i] = gl_canon(in[2 * i]); im[i] = gl_canon(in[2 * i + 1]); }
+}
+__global__ void interleave_big_kernel(const u64 *re, const u64 *im, size_t n, u64 *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[2 * i] = re[i]; out[2 * i + 1] = im[i]; }
+}
+
+struct zk_fri_commit {
+    zk_ctx *ctx; zk_stark_config cfg;
+    u32 log_n, lgL, ar[64], nl, done; bool finished;
+    u64 *F, *Fco;                       // layer-0 values (re | im, leaf order), coefficient buffer
+    u64 *cre, *cim; size_t cur; u32 cur_lg; u64 shift;
+    const u64 *vre[9], *vim[9]; u64 *lvl[8];
+    std::vector<void *> owned;
+};
+
+extern "C" {
+
+int32_t zk_fri_combine(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_oracles, zk_batch *const *oracles, uint32_t n_batches,
+                       const zk_fri_batch *batches, const uint64_t alpha[2], uint64_t *final_values_out) {
+    if (!ctx || !cfg || !oracles || !batches || !alpha || !final_values_out || n_oracles == 0 || n_oracles > 8 || n_batches == 0 || n_batches > FRI_MAX_BATCHES)
+        return ZK_ERR_INVALID_ARG;
+    if (cfg->rate_bits > 4 || cfg->cap_height > 8) return ctx->fail(ZK_ERR_INVALID_ARG, "fri combine: unsupported parameters");
+    for (u32 o = 0; o < n_oracles; o++) if (!oracles[o] || oracles[o]->ctx != ctx) return ctx->fail(ZK_ERR_INVALID_ARG, "fri combine: oracle of another context");
+    hipSetDevice(ctx->device);
+    FriBatchDesc desc[FRI_MAX_BATCHES];
+    for (u32 b = 0; b < n_batches; b++) {
+        if (!batches[b].polys) return ctx->fail(ZK_ERR_INVALID_ARG, "fri combine: batch without polynomials");
+        desc[b].point[0] = gl_canon(batches[b].point[0]); desc[b].point[1] = gl_canon(batches[b].point[1]);
+        desc[b].n_polys = batches[b].n_polys; desc[b].polys = batches[b].polys;
+    }
+    const size_t L = (size_t)1 << (oracles[0]->log_n + cfg->rate_bits);
+    ZkOwned own(ctx);
+    u64 *d_alpha = (u64 *)own.get(2 * sizeof(u64)), *F = (u64 *)own.get(2 * L * sizeof(u64)), *out = (u64 *)own.get(2 * L * sizeof(u64));
+    if (!d_alpha || !F || !out) return ctx->fail(ZK_ERR_OOM, "fri combine: out of device memory");
+    u64 ha[2] = {gl_canon(alpha[0]), gl_canon(alpha[1])};
+    int32_t rc = zk_dev_upload(ctx, d_alpha, ha, sizeof ha);
+    if (rc == ZK_OK) rc = zk_fri_final_values_dev(ctx, *cfg, d_alpha, oracles, n_oracles, desc, n_batches, F);
+    if (rc == ZK_OK) {
+        ZK_LAUNCH(ctx, "fri_interleave", interleave_big_kernel, g1(L), dim3(256), 0, (const u64 *)F, (const u64 *)(F + L), L, out);
+        rc = zk_dev_download(ctx, final_values_out, out, 2 * L * sizeof(u64));
+    }
+    return rc;
+}
+
+int32_t zk_fri_commit_begin(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t log_n, const uint64_t *final_values, zk_fri_commit **out) {
+    if (!ctx || !cfg || !final_values || !out) return ZK_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->rate_bits > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits < 2 || cfg->fri_arity_bits > 6 || log_n > 26 || log_n + cfg->rate_bits < cfg->cap_height)
+        return ctx->fail(ZK_ERR_INVALID_ARG, "fri commit: unsupported FRI parameters");
+    hipSetDevice(ctx->device);
+    zk_fri_commit *s = new zk_fri_commit();
+    s->ctx = ctx; s->cfg = *cfg; s->log_n = log_n; s->lgL = log_n + cfg->rate_bits; s->done = 0; s->finished = false;
+    zk_fri_arities(*cfg, log_n, s->ar, &s->nl);
+    const size_t L = (size_t)1 << s->lgL;
+    if (s->nl > 8) { delete s; return ctx->fail(ZK_ERR_INVALID_ARG, "fri commit: more than 8 reduction layers"); }
+    s->F = (u64 *)ctx->alloc(2 * L * sizeof(u64)); s->Fco = (u64 *)ctx->alloc(2 * L * sizeof(u64));
+    u64 *tmp = (u64 *)ctx->alloc(2 * L * sizeof(u64));
+    if (s->F) s->owned.push_back(s->F);
+    if (s->Fco) s->owned.push_back(s->Fco);
+    int32_t rc = (s->F && s->Fco && tmp) ? zk_dev_upload(ctx, tmp, final_values, 2 * L * sizeof(u64)) : ZK_ERR_OOM;
+    if (rc == ZK_OK) {
+        ZK_LAUNCH(ctx, "fri_deinterleave", deinterleave_kernel, g1(L), dim3(256), 0, (const u64 *)tmp, L, s->F, s->F + L);
+        // coefficients of the final polynomial on the LDE domain: coset_ifft(g) of the values (leaf order -> natural coefficients)
+        TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), s->lgL);
+        rc = zk_ntt_dit(ctx, s->F, L, s->Fco, L, s->lgL, 2, 1, nullptr, &post, 0, nullptr, 0);
+    }
+    ctx->release(tmp);
+    if (rc != ZK_OK) { for (void *q : s->owned) ctx->release(q); delete s; return rc; }
+    s->vre[0] = s->F; s->vim[0] = s->F + L; s->cre = s->Fco; s->cim = s->Fco + L; s->cur = L; s->cur_lg = s->lgL; s->shift = GL_GEN;
+    *out = s;
+    return ZK_OK;
+}
+
+int32_t zk_fri_commit_layers(const zk_fri_commit *s, uint32_t *n_layers, uint32_t *layers_done) {
+    if (!s) return ZK_ERR_INVALID_ARG;
+    if (n_layers) *n_layers = s->nl;
+    if (layers_done) *layers_done = s->done;
+    return ZK_OK;
+}
+
+int32_t zk_fri_fold_commit_layer(zk_fri_commit *s, zk_challenger *ch, uint64_t *cap_out, uint64_t beta_out[2]) {
+    if (!s || !ch || !cap_out || !beta_out || ch->ctx != s->ctx) return ZK_ERR_INVALID_ARG;
+    zk_ctx *ctx = s->ctx;
+    if (s->done >= s->nl || s->finished) return ctx->fail(ZK_ERR_INVALID_ARG, "fri commit: every reduction layer has been committed");
+    hipSetDevice(ctx->device);
+    const zk_stark_config &cfg = s->cfg;
+    const u32 l = s->done, arity = 1u << s->ar[l], capw = 4u << cfg.cap_height;
+    const size_t n_leaves = s->cur >> s->ar[l];
+    const u32 depth = s->cur_lg - s->ar[l];
+    const size_t n_dig = zk_level_offset(n_leaves, depth - cfg.cap_height + 1);
+    s->lvl[l] = (u64 *)ctx->alloc(n_dig * 4 * sizeof(u64));
+    u64 *d_beta = (u64 *)ctx->alloc(2 * sizeof(u64));
+    const size_t nxt = s->cur >> s->ar[l];
+    u64 *nco = (u64 *)ctx->alloc(2 * nxt * sizeof(u64)), *nva = (u64 *)ctx->alloc(2 * nxt * sizeof(u64));
+    for (void *q : {(void *)s->lvl[l], (void *)nco, (void *)nva}) if (q) s->owned.push_back(q);
+    if (!s->lvl[l] || !d_beta || !nco || !nva) { ctx->release(d_beta); return ctx->fail(ZK_ERR_OOM, "fri commit: out of device memory"); }
+    if (!zk_fri_leaf_hash_mfma(ctx, s->vre[l], s->vim[l], n_leaves, arity, s->lvl[l]))
+        ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_kernel, g1(n_leaves), dim3(256), 0, s->vre[l], s->vim[l], n_leaves, arity, s->lvl[l], ctx->force_redo);
+    zk_merkle_levels(ctx, s->lvl[l], n_leaves, cfg.cap_height);
+    const u64 *cap = s->lvl[l] + 4 * zk_level_offset(n_leaves, depth - cfg.cap_height);
+    { TOpList a = {}; a.n = 2; a.op[0].kind = TOP_OBSERVE; a.op[0].src = cap; a.op[0].n = capw;
+      a.op[1].kind = TOP_GET; a.op[1].dst = d_beta; a.op[1].n = 2; zk_transcript_run(ctx, ch->d, a); }
+    ZK_LAUNCH(ctx, "fri_fold", fri_fold_kernel, g1(nxt), dim3(256), 0, (const u64 *)s->cre, (const u64 *)s->cim, nxt, arity, (const u64 *)d_beta, nco, nco + nxt);
+    s->cre = nco; s->cim = nco + nxt;
+    s->shift = gl_pow(s->shift, arity);
+    s->cur = nxt; s->cur_lg = depth;
+    TwoLevel pre = zk_scale_table(ctx, s->shift, 1, s->cur_lg);
+    int32_t rc = zk_ntt_dif(ctx, nco, s->cur, nva, s->cur, s->cur_lg, 2, 0, &pre, 0, 0);
+    s->vre[l + 1] = nva; s->vim[l + 1] = nva + s->cur;
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, cap_out, cap, capw * sizeof(u64));
+    if (rc == ZK_OK) rc = zk_dev_download(ctx, beta_out, d_beta, 2 * sizeof(u64));
+    ctx->release(d_beta);
+    if (rc == ZK_OK) s->done++;
+    return rc;
+}
+
+int32_t zk_fri_commit_finish(zk_fri_commit *s, zk_challenger *ch, uint64_t *final_poly_out, uint32_t *len_ext) {
+    if (!s || !ch || !final_poly_out || ch->ctx != s->ctx) return ZK_ERR_INVALID_ARG;
+    zk_ctx *ctx = s->ctx;
+    if (s->done != s->nl || s->finished) return ctx->fail(ZK_ERR_INVALID_ARG, "fri commit: layers outstanding, or already finished");
+    hipSetDevice(ctx->device);
+    const u32 flen = (u32)(s->cur >> s->cfg.rate_bits);          // coeffs.truncate(len >> rate_bits)
+    u64 *d = (u64 *)ctx->alloc(2 * (size_t)flen * sizeof(u64));
+    if (!d) return ctx->fail(ZK_ERR_OOM, "fri commit: out of device memory");
+    ZK_LAUNCH(ctx, "interleave", interleave_kernel, g1(flen), dim3(256), 0, (const u64 *)s->cre, (const u64 *)s->cim, flen, d);
+    { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d; a.op[0].n = 2 * flen; zk_transcript_run(ctx, ch->d, a); }
+    int32_t rc = zk_dev_download(ctx, final_poly_out, d, 2 * (size_t)flen * sizeof(u64));
+    ctx->release(d);
+    if (rc == ZK_OK) { s->finished = true; if (len_ext) *len_ext = flen; }
+    return rc;
+}
+
+size_t zk_fri_query_size_words(const zk_fri_commit *s, uint32_t n_oracles, zk_batch *const *oracles) {
+    if (!s || !oracles || n_oracles == 0 || n_oracles > 8) return 0;
+    size_t per = 0;
+    for (u32 o = 0; o < n_oracles; o++) { if (!oracles[o]) return 0; per += oracles[o]->n_cols + (size_t)4 * (s->lgL - s->cfg.cap_height); }
+    u32 lg = s->lgL;
+    for (u32 l = 0; l < s->nl; l++) { lg -= s->ar[l]; per += (2u << s->ar[l]) + 4 * (size_t)(lg - s->cfg.cap_height); }
+    return per;
+}
+
+int32_t zk_fri_query(zk_fri_commit *s, uint32_t n_oracles, zk_batch *const *oracles, uint32_t x_index, uint64_t *out, size_t cap_words, size_t *len_words) {
+    if (!s || !oracles || !out || n_oracles == 0 || n_oracles > 8) return ZK_ERR_INVALID_ARG;
+    zk_ctx *ctx = s->ctx;
+    if (s->done != s->nl) return ctx->fail(ZK_ERR_INVALID_ARG, "fri query: commit phase not complete");
+    const size_t L = (size_t)1 << s->lgL;
+    if (x_index >= L) return ctx->fail(ZK_ERR_INVALID_ARG, "fri query: index outside the LDE domain");
+    for (u32 o = 0; o < n_oracles; o++)
+        if (!oracles[o] || oracles[o]->ctx != ctx || oracles[o]->log_n != s->log_n || oracles[o]->rate_bits != s->cfg.rate_bits || oracles[o]->cap_height != s->cfg.cap_height)
+            return ctx->fail(ZK_ERR_INVALID_ARG, "fri query: oracle does not match the commit phase");
+    const size_t per = zk_fri_query_size_words(s, n_oracles, oracles);
+    if (len_words) *len_words = per;
+    if (cap_words < per) return ZK_ERR_BUFFER_TOO_SMALL;
+    hipSetDevice(ctx->device);
+    ZkOwned own(ctx);
+    u64 *d_idx = (u64 *)own.get(sizeof(u64)), *d_out = (u64 *)own.get(per * sizeof(u64));
+    if (!d_idx || !d_out) return ctx->fail(ZK_ERR_OOM, "fri query: out of device memory");
+    u64 hx = x_index;
+    int32_t rc = zk_dev_upload(ctx, d_idx, &hx, sizeof hx);
+    if (rc) return rc;
+    QueryParams q = {};
+    q.n_layers = s->nl; q.cap_height = s->cfg.cap_height; q.lgL = s->lgL; q.n_oracles = n_oracles;
+    for (u32 o = 0; o < n_oracles; o++) { q.lde[o] = oracles[o]->lde; q.levels[o] = oracles[o]->levels; q.n_cols[o] = oracles[o]->n_cols; }
+    for (u32 l = 0; l < s->nl; l++) { q.lre[l] = s->vre[l]; q.lim[l] = s->vim[l]; q.llevels[l] = s->lvl[l]; q.arity_bits[l] = s->ar[l]; }
+    q.idx = d_idx; q.out = d_out; q.per_query = per;
+    ZK_LAUNCH(ctx, "fri_query_gather", fri_query_kernel, dim3(1), dim3(256), 0, q);
+    return zk_dev_download(ctx, out, d_out, per * sizeof(u64));
+}
+
+int32_t zk_fri_commit_free(zk_fri_commit *s) {
+    if (!s) return ZK_ERR_INVALID_ARG;
+    hipStreamSynchronize(s->ctx->stream);
+    for (void *q : s->owned) s->ctx->release(q);
+    delete s;
+    return ZK_OK;
+}
+
+}  // extern "C"

@@ -122,7 +122,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         if (tables[t].air->n_public_inputs && !tables[t].public_inputs) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: public inputs missing");
     }
     hipSetDevice(ctx->device);
-    ctx->wait_pending_uploads();                     // traces prefetched with zk_trace_upload_async (device-side wait)
+    for (u32 t = 0; t < nt; t++) if (tables[t].trace_on_device) ctx->wait_upload(tables[t].trace);   // zk_trace_upload_async prefetches (device-side wait)
     const u32 nch = cfg.num_challenges, capw = 4u << cfg.cap_height;
     std::vector<TableLayout> lay(nt);
     size_t total = 2;
@@ -194,7 +194,10 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
     std::vector<const u64 *> d_trace(nt, nullptr);
 
     // ---- commit every trace; observe every trace cap, then the public values; draw the lookup/CTL challenges
+    // (phase scopes carry upstream's `timed!` names -- the TimingTree the reference creates at ops/src/lib.rs:52 -- next to the
+    // per-kernel labels of the profiler: "phase: ..." entries of zk_profile_get)
     { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_INIT; zk_transcript_run(ctx, ch, a); }
+    std::unique_ptr<ProfScope> phase(new ProfScope(ctx, "phase: compute all trace commitments"));
     for (u32 t = 0; t < nt && rc == ZK_OK; t++) {
         const size_t n = (size_t)1 << tables[t].log_n;
         const u32 C = tables[t].air->n_trace_cols;
@@ -214,6 +217,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + lay[t].o_trace_cap; a.op[0].n = capw;
         zk_transcript_run(ctx, ch, a);
     }
+    phase.reset();
     if (rc) return rc;
     for (u32 t = 0; t < nt; t++) if (tables[t].air->n_public_inputs) {
         TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_pub[t]; a.op[0].n = tables[t].air->n_public_inputs;
@@ -229,6 +233,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         const TableLayout &y = lay[t];
         { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_COMPACT; zk_transcript_run(ctx, ch, a); }     // init_challenger_state
         if (A) {
+            ProfScope ph(ctx, "phase: compute auxiliary polynomials commitment");
             u64 *d_aux = (u64 *)ctx->alloc((size_t)A * n * sizeof(u64));
             if (!d_aux) { rc = ZK_ERR_OOM; break; }
             rc = zk_aux_columns_dev(ctx, air, dair[t].d_helpers, nch, d_chal, d_trace[t], log_n, d_aux);
@@ -242,9 +247,12 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_GET; a.op[0].dst = d_alphas; a.op[0].n = nch; zk_transcript_run(ctx, ch, a); }
         u64 *d_q = (u64 *)ctx->alloc((size_t)nch * L * sizeof(u64));
         if (!d_q) { rc = ZK_ERR_OOM; break; }
-        rc = zk_quotient_dev(ctx, dair[t], cfg, trace_b[t], aux_b[t], d_pub[t], d_chal, d_alphas, d_q);
+        {
+            ProfScope ph(ctx, "phase: compute quotient polys");
+            rc = zk_quotient_dev(ctx, dair[t], cfg, trace_b[t], aux_b[t], d_pub[t], d_chal, d_alphas, d_q);
+        }
         // the nch*L natural-order coefficients are Q = nch << rate_bits polynomials of n coefficients, back to back
-        if (rc == ZK_OK) rc = zk_batch_commit_dev(ctx, d_q, log_n, Q, cfg.rate_bits, cfg.cap_height, 0, &quot_b[t]);
+        if (rc == ZK_OK) { ProfScope ph(ctx, "phase: compute quotient commitment"); rc = zk_batch_commit_dev(ctx, d_q, log_n, Q, cfg.rate_bits, cfg.cap_height, 0, &quot_b[t]); }
         ctx->release(d_q);
         if (rc) break;
         scratch_probe(ctx, d_zeta + 7);
@@ -254,6 +262,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         ZK_LAUNCH(ctx, "zeta", zeta_kernel, dim3(1), dim3(1), 0, d_zeta, log_n, gl_root(log_n), ctx->d_err);
 
         // ---- StarkOpeningSet::new: every coefficient polynomial at zeta, trace and aux also at g*zeta, Z columns at 1
+        std::unique_ptr<ProfScope> ph_open(new ProfScope(ctx, "phase: construct the opening set"));
         rc = zk_eval_cols_at(ctx, trace_b[t]->coeffs, n, log_n, C, d_zeta, d_proof + y.fri.o_local);
         if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, trace_b[t]->coeffs, n, log_n, C, d_zeta + 2, d_proof + y.fri.o_next);
         if (rc == ZK_OK && A) rc = zk_eval_cols_at(ctx, aux_b[t]->coeffs, n, log_n, A, d_zeta, d_proof + y.fri.o_aux);
@@ -266,6 +275,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
             ZK_LAUNCH(ctx, "take_re", take_re_kernel, dim3(1), dim3(64), 0, (const u64 *)zs, nch, d_proof + y.fri.o_zs);
             ctx->release(zs);
         }
+        ph_open.reset();
         if (rc) break;
         // challenger.observe_openings(&openings.to_fri_openings()): zeta batch (local | aux | quotient), g*zeta batch, then Z(1)
         {
@@ -279,7 +289,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
             a.n = k;
             zk_transcript_run(ctx, ch, a);
         }
-        rc = zk_fri_prove_dev(ctx, cfg, ch, trace_b[t], aux_b[t], quot_b[t], d_zeta, d_proof, y.fri);
+        { ProfScope ph(ctx, "phase: compute openings proof"); rc = zk_fri_prove_dev(ctx, cfg, ch, trace_b[t], aux_b[t], quot_b[t], d_zeta, d_proof, y.fri); }
     }
 
     // ---- the only host synchronisation of the proof: fetch the proof bytes and the device error word

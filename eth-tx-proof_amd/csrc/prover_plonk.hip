@@ -325,7 +325,7 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
     const zk_stark_config &cfg = st->cfg;
     const zk_plonk_circuit &c = st->c;
     hipSetDevice(ctx->device);
-    ctx->wait_pending_uploads();
+    if (wires_on_device) ctx->wait_upload(wires);
     const u32 nch = cfg.num_challenges, qdf = c.quotient_degree_factor, R = c.num_routed_wires, W = c.num_wires, NC = c.num_constants;
     const u32 k = c.degree_bits, lgL = k + cfg.rate_bits, nchunks = R / qdf, npp = nchunks - 1, capw = 4u << cfg.cap_height, NZ = nch * (1 + npp), Q = nch * qdf;
     const size_t n = (size_t)1 << k, L = (size_t)1 << lgL;

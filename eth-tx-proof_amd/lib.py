@@ -13,7 +13,7 @@ import numpy as np
 from ._abi import ERRORS, StarkConfig
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.path.join(_CSRC, "libzkgl_hip.so")
+_SO = os.environ.get("ZK_LIB_PATH") or os.path.join(_CSRC, "libzkgl_hip.so")      # ZK_LIB_PATH: A/B experiments with another build of the library
 _HEADER = os.path.join(os.path.dirname(_CSRC), "..", "include", "zkgl.h")
 _lib = None
 
@@ -495,3 +495,66 @@ def prove_plonk(state, wires, public_inputs):
                               C.c_size_t(n), C.byref(ln))
     state.ctx._chk(rc, "zk_prove_plonk")
     return out[:ln.value]
+
+
+# ---- the FRI prover piece by piece (zk_fri_combine, zk_fri_commit_*, zk_fri_fold_commit_layer, zk_fri_query)
+def fri_combine(ctx, cfg, oracles, batches, alpha):
+    """zk_fri_combine: the final values (L x 2 uint64, leaf order) of the batch combination for a given alpha"""
+    from . import _abi
+    hs = (C.c_void_p * len(oracles))(*[o.h for o in oracles])
+    arr, keep = _abi.fri_instance(batches)
+    L = 1 << (oracles[0].log_n + cfg.rate_bits)
+    out = np.empty((L, 2), dtype=np.uint64)
+    al = _u64(alpha)
+    ctx._chk(lib().zk_fri_combine(ctx.h, C.byref(cfg), C.c_uint32(len(oracles)), hs, C.c_uint32(len(batches)), arr, _p(al), _p(out)), "zk_fri_combine")
+    del keep
+    return out
+
+
+class FriCommit:
+    """zk_fri_commit: the commit phase of one FRI proof, one reduction layer per call"""
+
+    def __init__(self, ctx, cfg, log_n, final_values):
+        self.ctx, self.cfg, self.log_n = ctx, cfg, log_n
+        self.h = C.c_void_p()
+        fv = _u64(final_values)
+        ctx._chk(lib().zk_fri_commit_begin(ctx.h, C.byref(cfg), C.c_uint32(log_n), _p(fv), C.byref(self.h)), "zk_fri_commit_begin")
+
+    def layers(self):
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        lib().zk_fri_commit_layers(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def fold_commit_layer(self, challenger):
+        cap = np.empty((1 << self.cfg.cap_height, 4), dtype=np.uint64)
+        beta = np.empty(2, dtype=np.uint64)
+        self.ctx._chk(lib().zk_fri_fold_commit_layer(self.h, challenger.h, _p(cap), _p(beta)), "zk_fri_fold_commit_layer")
+        return cap, beta
+
+    def finish(self, challenger):
+        out = np.empty(2 << (self.log_n + self.cfg.rate_bits), dtype=np.uint64)
+        ln = C.c_uint32(0)
+        self.ctx._chk(lib().zk_fri_commit_finish(self.h, challenger.h, _p(out), C.byref(ln)), "zk_fri_commit_finish")
+        return out[:2 * ln.value].copy()
+
+    def query(self, oracles, x_index):
+        hs = (C.c_void_p * len(oracles))(*[o.h for o in oracles])
+        f = lib().zk_fri_query_size_words
+        f.restype = C.c_size_t
+        n = f(self.h, C.c_uint32(len(oracles)), hs)
+        out = np.empty(n, dtype=np.uint64)
+        ln = C.c_size_t(0)
+        self.ctx._chk(lib().zk_fri_query(self.h, C.c_uint32(len(oracles)), hs, C.c_uint32(x_index), _p(out), C.c_size_t(n), C.byref(ln)), "zk_fri_query")
+        return out[:ln.value]
+
+    def free(self):
+        if self.h:
+            lib().zk_fri_commit_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass

@@ -110,7 +110,11 @@ class AggProof:
     """Monoid over AggregatableProof (lib.rs:67-82): Plonk recursion, not built yet."""
 
     def combine(self, a, b):
-        raise FatalError("generate_agg_proof: recursive aggregation is outside the built hot path (SURVEY.md 8f-2)")
+        # the Plonk PROVER of the recursion half exists (lib.prove_plonk, bit-exact against its oracle on circuits given as data);
+        # the aggregation CIRCUIT (gate set, recursive verifier gadgets, witness generator) lives in crates that are absent from the
+        # reference tree, so there is nothing honest to prove here
+        raise FatalError("generate_agg_proof: the aggregation circuit is not available (SURVEY.md 8f-2, A10); zk_prove_plonk proves "
+                         "circuits given as data")
 
     def empty(self):
         raise NotImplementedError("empty agg proof")          # lib.rs:78-81 unimplemented!
@@ -121,4 +125,5 @@ class BlockProof:
         self.prev = prev
 
     def execute(self, input):
-        raise FatalError("generate_block_proof: block circuit is outside the built hot path (SURVEY.md 8f-2)")
+        raise FatalError("generate_block_proof: the block circuit is not available (SURVEY.md 8f-2, A10); zk_prove_plonk proves "
+                         "circuits given as data")

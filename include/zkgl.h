@@ -76,9 +76,10 @@ int32_t zk_dev_download(zk_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 int32_t zk_host_alloc(zk_ctx *ctx, size_t bytes, void **h_ptr);
 int32_t zk_host_free(zk_ctx *ctx, void *h_ptr);
 /* Prefetch for a single worker: start uploading the NEXT unit's trace (n_words u64, pinned or pageable) on the context's copy
- * stream and return at once; *d_ptr is device memory owned by the context (zk_dev_free it after the proof).  The next call on this
- * context that enqueues work (e.g. zk_prove_tables with trace_on_device = 1 and this pointer) first waits, on the device, for
- * every pending upload.  Call it BEFORE the zk_prove_tables of the current unit so that the copy overlaps that proof. */
+ * stream and return at once; *d_ptr is device memory owned by the context (zk_dev_free it after the proof).  zk_prove_tables /
+ * zk_prove_plonk given this pointer (trace_on_device = 1) first wait, on the device, for the upload that fills it -- and only for
+ * that one, so a prefetch of the unit after next never holds a proof back.  Call it BEFORE the zk_prove_tables of the current
+ * unit so that the copy overlaps that proof. */
 int32_t zk_trace_upload_async(zk_ctx *ctx, const uint64_t *trace, size_t n_words, uint64_t **d_ptr);
 
 /* ------------------------------------------------------------------ field / NTT
@@ -292,6 +293,30 @@ size_t zk_fri_instance_proof_size_words(const zk_stark_config *cfg, uint32_t log
 int32_t zk_fri_prove_instance(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_oracles, zk_batch *const *oracles,
                               uint32_t n_batches, const zk_fri_batch *batches, zk_challenger *ch, uint64_t *fri_proof_out,
                               size_t cap_words, size_t *len_words);
+
+/* The same FRI prover piece by piece (SURVEY.md 8b "finer-grained"), one upstream item per call, synchronous:
+ *   zk_fri_combine            the batch combination of PolynomialBatch::prove_openings for a given alpha: final_values_out = the
+ *                             2^(log_n + rate_bits) extension values of sum_b alpha^(..) (P_b - P_b(z_b)) / (X - z_b) on the LDE coset,
+ *                             in leaf (bit-reversed) order, [re, im] interleaved  (upstream: lde_final_values after reverse_index_bits)
+ *   zk_fri_commit_begin       takes such values (host) and holds the commit-phase state on the device
+ *   zk_fri_fold_commit_layer  one iteration of fri_committed_trees: Merkle tree over the current values (leaves of 2^arity_bits
+ *                             extension values), cap observed by `ch`, beta drawn from `ch`, coefficients folded, values of the
+ *                             next layer = coset_fft(shift^arity).  cap_out: 2^cap_height x 4 words
+ *   zk_fri_commit_finish      final polynomial (len >> rate_bits coefficients), observed by `ch`; out: 2 * len_ext words
+ *   zk_fri_query              fri_prover_query_round(x_index): per oracle (leaf row, Merkle path), per layer (2^arity_bits
+ *                             extension evaluations, Merkle path) -- the words of one query round of the FriProof layout above
+ * The proof of work between finish and the queries is zk_pow_grind on the challenger's state. */
+typedef struct zk_fri_commit zk_fri_commit;
+int32_t zk_fri_combine(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_oracles, zk_batch *const *oracles, uint32_t n_batches,
+                       const zk_fri_batch *batches, const uint64_t alpha[2], uint64_t *final_values_out);
+int32_t zk_fri_commit_begin(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t log_n, const uint64_t *final_values, zk_fri_commit **out);
+int32_t zk_fri_commit_layers(const zk_fri_commit *s, uint32_t *n_layers, uint32_t *layers_done);
+int32_t zk_fri_fold_commit_layer(zk_fri_commit *s, zk_challenger *ch, uint64_t *cap_out, uint64_t beta_out[2]);
+int32_t zk_fri_commit_finish(zk_fri_commit *s, zk_challenger *ch, uint64_t *final_poly_out, uint32_t *len_ext);
+size_t zk_fri_query_size_words(const zk_fri_commit *s, uint32_t n_oracles, zk_batch *const *oracles);
+int32_t zk_fri_query(zk_fri_commit *s, uint32_t n_oracles, zk_batch *const *oracles, uint32_t x_index, uint64_t *out, size_t cap_words,
+                     size_t *len_words);
+int32_t zk_fri_commit_free(zk_fri_commit *s);
 
 /* ------------------------------------------------------------------ Plonk-shaped proof
  * What generate_txn_proof / generate_agg_proof / generate_block_proof (/root/reference/ops/src/lib.rs:52,72,95) spend their time in

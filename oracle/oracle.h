@@ -117,6 +117,8 @@ int32_t orc_fri_prove(const zk_stark_config *cfg, const orc_batch *trace_b, cons
                       orc_challenger *ch, const uint64_t zeta[2], uint64_t *out, size_t cap_words, size_t *len_words);
 int32_t orc_fri_prove_instance(const zk_stark_config *cfg, uint32_t n_oracles, const orc_batch *const *oracles, uint32_t n_batches,
                                const zk_fri_batch *batches, orc_challenger *ch, uint64_t *out, size_t cap_words, size_t *len_words);
+int32_t orc_fri_combine(const zk_stark_config *cfg, uint32_t n_oracles, const orc_batch *const *oracles, uint32_t n_batches,
+                        const zk_fri_batch *batches, const uint64_t alpha[2], uint64_t *out);
 size_t orc_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const orc_table *tables);
 
 /* plonky2::plonk::{prover, verifier} over a circuit given as plain data (zk_plonk_circuit, include/zkgl.h); plonk.c */

@@ -270,6 +270,35 @@ def fri_prove(cfg, trace_batch, aux_batch, quot_batch, challenger, zeta, cap_wor
     return rc, out[:ln.value]
 
 
+def _fri_batches(batches):
+    class FriPoly(C.Structure):
+        _fields_ = [("oracle_index", C.c_uint32), ("polynomial_index", C.c_uint32)]
+
+    class FriBatch(C.Structure):
+        _fields_ = [("point", C.c_uint64 * 2), ("n_polys", C.c_uint32), ("reserved", C.c_uint32), ("polys", C.POINTER(FriPoly))]
+    arr = (FriBatch * len(batches))()
+    keep = []
+    for i, (pt, polys) in enumerate(batches):
+        pa = (FriPoly * max(1, len(polys)))(*[FriPoly(int(o), int(k)) for o, k in polys])
+        keep.append(pa)
+        arr[i].point[0], arr[i].point[1] = int(pt[0]), int(pt[1])
+        arr[i].n_polys = len(polys)
+        arr[i].polys = C.cast(pa, C.POINTER(FriPoly))
+    return arr, keep
+
+
+def fri_combine(cfg, oracles, batches, alpha):
+    """counterpart of zk_fri_combine: lde_final_values (L x 2, leaf order) for a given alpha"""
+    arr, keep = _fri_batches(batches)
+    hs = (C.c_void_p * len(oracles))(*[o.h for o in oracles])
+    L = 1 << (oracles[0].log_n + cfg.rate_bits)
+    out = np.empty((L, 2), dtype=np.uint64)
+    al = u64(alpha)
+    rc = lib().orc_fri_combine(C.byref(cfg), C.c_uint32(len(oracles)), hs, C.c_uint32(len(batches)), arr, _p(al), _p(out))
+    assert rc == 0, rc
+    return out
+
+
 def fri_prove_instance(cfg, oracles, batches, challenger, cap_words=1 << 23):
     """counterpart of zk_fri_prove_instance: oracles = [Batch], batches = [(point_ext, [(oracle, poly)])]"""
     class FriPoly(C.Structure):

@@ -370,3 +370,247 @@ def fri_reduction_arity_bits(degree_bits, rate_bits=1, cap_height=4, arity_bits=
         out.append(arity_bits)
         d -= arity_bits
     return out
+
+
+# ---------------------------------------------------------------- a whole unit proof, in plain Python (tiny sizes only)
+# Second, independent restatement of what oracle/stark.c does (starky prove_with_commitment + plonky2 fri_proof):
+# same inputs, same proof-word layout (include/zkgl.h), written from the appendix with Python integers and lists, sharing no code
+# with the C oracle -- tests/test_oracle_cpu.py compares the two word for word at 2^4 .. 2^6 rows.  It narrows the single-author
+# risk of stark.c; parity with upstream stays unpinned (no vector exists).
+def poly_eval_ext(coeffs, z):
+    acc = (0, 0)
+    for c in reversed(coeffs):
+        acc = ext_add(ext_mul(acc, z), (c % P, 0))
+    return acc
+
+
+def commit_values(cols, rate_bits, cap_height):
+    """PolynomialBatch::from_values: (coeffs per column, leaves (rows, bit-reversed order), cap, digests-by-level)"""
+    coeffs = [ifft(c) for c in cols]
+    return commit_coeffs(coeffs, rate_bits, cap_height)
+
+
+def commit_coeffs(coeffs, rate_bits, cap_height):
+    n = len(coeffs[0])
+    lg = (n << rate_bits).bit_length() - 1
+    ldes = [coset_fft(c + [0] * ((n << rate_bits) - n), MULTIPLICATIVE_GROUP_GENERATOR) for c in coeffs]
+    leaves = [[ldes[c][bitrev(r, lg)] for c in range(len(coeffs))] for r in range(n << rate_bits)]
+    cap, levels = _tree_levels([hash_or_noop(l) for l in leaves], cap_height)
+    return {"coeffs": coeffs, "leaves": leaves, "cap": cap, "levels": levels}
+
+
+def _tree_levels(digests, cap_height):
+    levels = [digests]
+    while len(levels[-1]) > (1 << cap_height):
+        cur = levels[-1]
+        levels.append([two_to_one(cur[2 * i], cur[2 * i + 1]) for i in range(len(cur) // 2)])
+    return levels[-1], levels
+
+
+def _path(levels, idx):
+    out = []
+    for k in range(len(levels) - 1):
+        out += levels[k][(idx >> k) ^ 1]
+    return out
+
+
+def _aux_columns(helpers, nch, chal, trace, n):
+    H = len(helpers)
+    cols = [[0] * n for _ in range(nch * (H + 1))]
+    for j in range(nch):
+        beta, gamma = chal[2 * j], chal[2 * j + 1]
+        for m, (a0, b0, a1, b1) in enumerate(helpers):
+            for r in range(n):
+                d0 = (trace[a0][r] + beta * trace[b0][r] + gamma) % P
+                d1 = (trace[a1][r] + beta * trace[b1][r] + gamma) % P
+                cols[j * H + m][r] = (inv(d0) + inv(d1)) % P
+        run = 0
+        for r in range(n - 1, -1, -1):
+            run = (run + sum(cols[j * H + m][r] for m in range(H))) % P
+            cols[nch * H + j][r] = run
+    return cols
+
+
+def _eval_program(instrs, consts, n_regs, local, nxt, pub, chal, alphas, z_last, l_first, l_last):
+    regs = [0] * max(1, n_regs)
+    acc = [0] * len(alphas)
+
+    def val(o):
+        k, i = o >> 24, o & 0xFFFFFF
+        if k == 0:
+            return regs[i]
+        if k == 1:
+            return local[i]
+        if k == 2:
+            return nxt[i]
+        return (consts[i] if k == 3 else pub[i] if k == 4 else chal[i]) % P
+    for op, dst, a, b in instrs:
+        x = val(a)
+        if op <= 2:
+            y = val(b)
+            regs[dst & 0xFFFFFF] = (x + y) % P if op == 0 else (x - y) % P if op == 1 else (x * y) % P
+        else:
+            c = x if op == 3 else x * (z_last if op == 4 else l_first if op == 5 else l_last) % P
+            acc = [(a_ * al + c) % P for a_, al in zip(acc, alphas)]
+    return acc
+
+
+def prove_tables(cfg, tables):
+    """cfg: dict(num_challenges, rate_bits, cap_height, proof_of_work_bits, fri_arity_bits, fri_final_poly_bits, num_query_rounds);
+    tables: list of dict(log_n, trace (cols x n ints), pub, instrs [(op,dst,a,b)], constants, n_regs, helpers [(a0,b0,a1,b1)]).
+    Returns the proof words (list of ints) in the layout of zk_prove_tables."""
+    nch, rb, ch_h = cfg["num_challenges"], cfg["rate_bits"], cfg["cap_height"]
+    assert rb == 1
+    g = MULTIPLICATIVE_GROUP_GENERATOR
+    out = [0x31465250474C4B5A, len(tables)]
+    ch = Challenger()
+    tb = []
+    for t in tables:
+        b = commit_values([list(c) for c in t["trace"]], rb, ch_h)
+        tb.append(b)
+        for h in b["cap"]:
+            ch.observe_many(h)
+    for t in tables:
+        ch.observe_many([x % P for x in t["pub"]])
+    chal = ch.get_n(2 * nch)
+    for t, b in zip(tables, tb):
+        k, n = t["log_n"], 1 << t["log_n"]
+        L, lgL = n << rb, t["log_n"] + rb
+        C, H = len(t["trace"]), len(t["helpers"])
+        A = nch * (H + 1) if H else 0
+        ch.compact()
+        out += [k, C, A] + [w for h in b["cap"] for w in h]
+        ab = None
+        if A:
+            ab = commit_values(_aux_columns(t["helpers"], nch, chal, t["trace"], n), rb, ch_h)
+            for h in ab["cap"]:
+                ch.observe_many(h)
+            out += [w for h in ab["cap"] for w in h]
+        alphas = ch.get_n(nch)
+        # ---- quotient: constraints on the coset g*<w_L>, / Z_H, coset_ifft, chunks of n
+        w_L, w_n = root_of_unity(lgL), root_of_unity(k)
+        sel_f, sel_l = [0] * n, [0] * n
+        sel_f[0], sel_l[n - 1] = 1, 1
+        lag_f = coset_fft(ifft(sel_f) + [0] * (L - n), g)
+        lag_l = coset_fft(ifft(sel_l) + [0] * (L - n), g)
+        gn = pow(g, n, P)
+        zh_inv = [inv((gn * pow(root_of_unity(rb), i, P) - 1) % P) for i in range(1 << rb)]
+        last = inv(w_n)
+        qv = [[0] * L for _ in range(nch)]
+        for i in range(L):
+            rl, rn = bitrev(i, lgL), bitrev((i + (1 << rb)) % L, lgL)
+            local = b["leaves"][rl] + (ab["leaves"][rl] if A else [])
+            nxt = b["leaves"][rn] + (ab["leaves"][rn] if A else [])
+            x = g * pow(w_L, i, P) % P
+            acc = _eval_program(t["instrs"], t["constants"], t["n_regs"], local, nxt, t["pub"], chal, alphas, (x - last) % P, lag_f[i], lag_l[i])
+            for j in range(nch):
+                qv[j][i] = acc[j] * zh_inv[i % (1 << rb)] % P
+        qco = []
+        for j in range(nch):
+            c = coset_ifft(qv[j], g)
+            qco += [c[s * n:(s + 1) * n] for s in range(1 << rb)]
+        qb = commit_coeffs(qco, rb, ch_h)
+        for h in qb["cap"]:
+            ch.observe_many(h)
+        out += [w for h in qb["cap"] for w in h]
+        zeta = ch.get_ext()
+        assert ext_pow(zeta, n) != (1, 0)
+        gz = ext_mul(zeta, (w_n, 0))
+        Q = len(qco)
+        o_local = [poly_eval_ext(c, zeta) for c in b["coeffs"]]
+        o_next = [poly_eval_ext(c, gz) for c in b["coeffs"]]
+        o_aux = [poly_eval_ext(c, zeta) for c in ab["coeffs"]] if A else []
+        o_auxn = [poly_eval_ext(c, gz) for c in ab["coeffs"]] if A else []
+        o_q = [poly_eval_ext(c, zeta) for c in qb["coeffs"]]
+        zs = [sum(ab["coeffs"][A - nch + j]) % P for j in range(nch)] if A else []
+        flat = lambda es: [w for e in es for w in e]
+        out += flat(o_local) + flat(o_next) + flat(o_aux) + flat(o_auxn) + zs + flat(o_q)
+        ch.observe_many(flat(o_local)); ch.observe_many(flat(o_aux)); ch.observe_many(flat(o_q))
+        ch.observe_many(flat(o_next)); ch.observe_many(flat(o_auxn))
+        for z in zs:
+            ch.observe_many([z, 0])
+        # ---- FRI: batches (zeta: trace|aux|quot) (g zeta: trace|aux) (1: Zs)
+        oracles = [b] + ([ab] if A else []) + [qb]
+        batches = [(zeta, b["coeffs"] + (ab["coeffs"] if A else []) + qb["coeffs"]), (gz, b["coeffs"] + (ab["coeffs"] if A else []))]
+        if A:
+            batches.append(((1, 0), ab["coeffs"][A - nch:]))
+        out += _fri_prove(cfg, k, oracles, batches, ch)
+    return out
+
+
+def _fri_prove(cfg, k, oracles, batches, ch):
+    rb, ch_h = cfg["rate_bits"], cfg["cap_height"]
+    n, L, lgL = 1 << k, (1 << k) << rb, k + rb
+    g = MULTIPLICATIVE_GROUP_GENERATOR
+    alpha = ch.get_ext()
+    final = [(0, 0)] * n
+    for bi, (z, polys) in enumerate(batches):
+        comp = []
+        for i in range(n):
+            acc = (0, 0)
+            for p in reversed(polys):
+                acc = ext_add(ext_mul(acc, alpha), (p[i] % P, 0))
+            comp.append(acc)
+        q, acc = [(0, 0)] * n, (0, 0)              # divide_by_linear: Horner from the top, drop the remainder, push a zero
+        for i in range(n - 1, -1, -1):
+            acc = ext_add(ext_mul(acc, z), comp[i])
+            if i > 0:
+                q[i - 1] = acc
+        sh = ext_pow(alpha, len(polys))
+        final = [ext_add(ext_mul(f, sh) if bi else (0, 0), qq) for f, qq in zip(final, q)]
+    coeffs = final + [(0, 0)] * (L - n)
+
+    def ext_coset_fft(cs, shift):
+        re, im = coset_fft([c[0] for c in cs], shift), coset_fft([c[1] for c in cs], shift)
+        return list(zip(re, im))
+    values = ext_coset_fft(coeffs, g)
+    ar = fri_reduction_arity_bits(k, rb, ch_h, cfg["fri_arity_bits"], cfg["fri_final_poly_bits"])
+    out = [len(ar)]
+    cur_lg, shift = lgL, g
+    layers = []
+    for a in ar:
+        arity = 1 << a
+        cur = 1 << cur_lg
+        br = [values[bitrev(i, cur_lg)] for i in range(cur)]
+        leaves = [[w for e in br[i * arity:(i + 1) * arity] for w in e] for i in range(cur // arity)]
+        cap, levels = _tree_levels([hash_or_noop(l) for l in leaves], ch_h)
+        for h in cap:
+            ch.observe_many(h)
+        out += [w for h in cap for w in h]
+        layers.append((leaves, levels, a))
+        beta = ch.get_ext()
+        nxt = []
+        for i in range(cur // arity):
+            acc = (0, 0)
+            for t in range(arity - 1, -1, -1):
+                acc = ext_add(ext_mul(acc, beta), coeffs[arity * i + t])
+            nxt.append(acc)
+        coeffs = nxt
+        shift = pow(shift, arity, P)
+        cur_lg -= a
+        values = ext_coset_fft(coeffs, shift)
+    flen = (1 << cur_lg) >> rb
+    out += [flen] + [w for e in coeffs[:flen] for w in e]
+    ch.observe_many([w for e in coeffs[:flen] for w in e])
+    # proof of work: smallest witness
+    st = list(ch.state)
+    for i, v in enumerate(ch.inp):
+        st[i] = v
+    pos, wit = len(ch.inp), 0
+    while True:
+        s2 = list(st); s2[pos] = wit
+        r = poseidon(s2)[7]
+        if (64 - r.bit_length()) >= cfg["proof_of_work_bits"]:
+            break
+        wit += 1
+    ch.observe(wit)
+    assert (64 - ch.get().bit_length()) >= cfg["proof_of_work_bits"]
+    out.append(wit)
+    for x in [c % L for c in ch.get_n(cfg["num_query_rounds"])]:
+        for o in oracles:
+            out += o["leaves"][x] + _path(o["levels"], x)
+        for leaves, levels, a in layers:
+            leaf = x >> a
+            out += leaves[leaf] + _path(levels, leaf)
+            x = leaf
+    return out

@@ -159,12 +159,11 @@ typedef struct {
     uint32_t n_batches; const gl2 *points; const uint32_t *cnt; const zk_fri_poly *const *polys;
 } fri_instance;
 
-/* PolynomialBatch::prove_openings + fri_proof */
-static int32_t fri_prove_instance(const zk_stark_config *cfg, const fri_instance *I, orc_challenger *ch, wr *w) {
+/* PolynomialBatch::prove_openings up to fri_proof: final_poly coefficients (length L, upper part zero) and its values on the LDE
+ * coset (natural order) for a given alpha */
+static void fri_final_poly(const zk_stark_config *cfg, const fri_instance *I, gl2 alpha, gl2 **coeffs_out, gl2 **values_out) {
     uint32_t log_n = I->oracles[0]->log_n, lgL = log_n + cfg->rate_bits;
     size_t n = (size_t)1 << log_n, L = (size_t)1 << lgL;
-    uint64_t ab[2]; orc_challenger_get_n(ch, 2, ab);
-    gl2 alpha = {ab[0], ab[1]};
     uint32_t nb = I->n_batches;
     gl2 *final_poly = (gl2 *)calloc(L, sizeof(gl2));
     gl2 *comp = (gl2 *)malloc(n * sizeof(gl2));
@@ -194,10 +193,21 @@ static int32_t fri_prove_instance(const zk_stark_config *cfg, const fri_instance
     }
     free(comp);
     /* lde(rate_bits).coset_fft(g) */
-    gl2 *coeffs = final_poly;           /* length L, upper part zero */
     gl2 *values = (gl2 *)malloc(L * sizeof(gl2));
-    memcpy(values, coeffs, L * sizeof(gl2));
+    memcpy(values, final_poly, L * sizeof(gl2));
     ext_fft_coset(values, lgL, GL_GEN);
+    *coeffs_out = final_poly; *values_out = values;
+}
+
+/* PolynomialBatch::prove_openings + fri_proof */
+static int32_t fri_prove_instance(const zk_stark_config *cfg, const fri_instance *I, orc_challenger *ch, wr *w) {
+    uint32_t log_n = I->oracles[0]->log_n, lgL = log_n + cfg->rate_bits;
+    size_t L = (size_t)1 << lgL;
+    uint64_t ab[2]; orc_challenger_get_n(ch, 2, ab);
+    gl2 alpha = {ab[0], ab[1]};
+    gl2 *final_poly, *values;
+    fri_final_poly(cfg, I, alpha, &final_poly, &values);
+    gl2 *coeffs = final_poly;           /* length L, upper part zero */
 
     /* fri_committed_trees */
     uint32_t ar[64], nl; fri_arities(cfg, log_n, ar, &nl);
@@ -501,6 +511,22 @@ int32_t orc_fri_prove(const zk_stark_config *cfg, const orc_batch *trace_b, cons
     return w.overflow ? ZK_ERR_BUFFER_TOO_SMALL : ZK_OK;
 }
 /* PolynomialBatch::prove_openings for any FriInstanceInfo (counterpart of zk_fri_prove_instance) */
+/* the counterpart of zk_fri_combine: lde_final_values in leaf (bit-reversed) order, [re, im] interleaved, for a given alpha */
+int32_t orc_fri_combine(const zk_stark_config *cfg, uint32_t n_oracles, const orc_batch *const *oracles, uint32_t n_batches,
+                        const zk_fri_batch *batches, const uint64_t alpha[2], uint64_t *out) {
+    if (!cfg || !oracles || !batches || !alpha || !out || n_oracles == 0 || n_batches == 0 || n_batches > 4) return ZK_ERR_INVALID_ARG;
+    gl2 pts[4]; uint32_t cnt[4]; const zk_fri_poly *pl[4];
+    for (uint32_t b = 0; b < n_batches; b++) { pts[b] = (gl2){gl_canon(batches[b].point[0]), gl_canon(batches[b].point[1])}; cnt[b] = batches[b].n_polys; pl[b] = batches[b].polys; }
+    fri_instance I = {n_oracles, oracles, n_batches, pts, cnt, pl};
+    gl2 *co, *va;
+    fri_final_poly(cfg, &I, (gl2){gl_canon(alpha[0]), gl_canon(alpha[1])}, &co, &va);
+    uint32_t lgL = oracles[0]->log_n + cfg->rate_bits;
+    size_t L = (size_t)1 << lgL;
+    for (size_t i = 0; i < L; i++) { gl2 v = va[bitrev32((uint32_t)i, lgL)]; out[2 * i] = v.a; out[2 * i + 1] = v.b; }
+    free(co); free(va);
+    return ZK_OK;
+}
+
 int32_t orc_fri_prove_instance(const zk_stark_config *cfg, uint32_t n_oracles, const orc_batch *const *oracles, uint32_t n_batches,
                                const zk_fri_batch *batches, orc_challenger *ch, uint64_t *out, size_t cap_words, size_t *len_words) {
     if (!n_oracles || n_oracles > 8 || !n_batches || n_batches > 4) return ZK_ERR_INVALID_ARG;

@@ -268,3 +268,65 @@ def test_prover_state_persists_compiled_kernels_on_disk(tmp_path):
     third = run()
     assert third["compiled"] == 1 and third["loaded"] == 0 and third["sha"] == first["sha"]
     assert open(path, "rb").read() == blob
+
+
+@pytest.mark.parametrize("log_n,widths,recursion", [(9, (20, 135, 20, 16), True), (12, (7, 5, 4), False)])
+def test_fri_piece_by_piece_equals_the_whole(ctx, zk, orc, log_n, widths, recursion):
+    """SURVEY.md 8b's finer-grained FRI exports: zk_fri_combine == the oracle's combination for the same alpha, and the commit
+    phase driven layer by layer (zk_fri_fold_commit_layer), its final polynomial and every query round (zk_fri_query) reproduce,
+    word for word, what the one-call prover zk_fri_prove_instance (== the oracle, tested above) puts into the FriProof."""
+    import eth_tx_proof_amd as E
+    import pyspec
+    P = 0xFFFFFFFF00000001
+    cfg = E.standard_recursion_config() if recursion else E.standard_fast_config()
+    rng = np.random.default_rng(100 + log_n)
+    gb, ob = [], []
+    for w in widths:
+        v = field_rand(rng, (w, 1 << log_n))
+        gb.append(ctx.batch_from_values(v, rate_bits=cfg.rate_bits, cap_height=cfg.cap_height))
+        ob.append(orc.Batch(v, rate_bits=cfg.rate_bits, cap_height=cfg.cap_height))
+    zeta = field_rand(rng, 2)
+    g = pyspec.root_of_unity(log_n)
+    inst = [(zeta, [(o, c) for o, w in enumerate(widths) for c in range(w)]),
+            ((int(zeta[0]) * g % P, int(zeta[1]) * g % P), [(len(widths) - 1, c) for c in range(2)])]
+    seed = field_rand(rng, 7)
+    whole_ch = ctx.challenger(); whole_ch.observe(seed)
+    whole = zk.fri_prove_instance(ctx, cfg, gb, inst, whole_ch)
+    # ---- the same proof in pieces
+    ch = ctx.challenger(); ch.observe(seed)
+    alpha = ch.get(2)
+    vals = zk.fri_combine(ctx, cfg, gb, inst, alpha)
+    assert (vals == orc.fri_combine(cfg, ob, inst, alpha)).all()
+    fc = zk.FriCommit(ctx, cfg, log_n, vals)
+    nl, done = fc.layers()
+    capw = 4 << cfg.cap_height
+    pos = 0
+    assert whole[pos] == nl; pos += 1
+    for l in range(nl):
+        cap, beta = fc.fold_commit_layer(ch)
+        assert (cap.ravel() == whole[pos:pos + capw]).all(), l
+        pos += capw
+    with pytest.raises(zk.ZkError):
+        fc.fold_commit_layer(ch)                       # no layer left
+    fin = fc.finish(ch)
+    assert whole[pos] == fin.size // 2; pos += 1
+    assert (fin == whole[pos:pos + fin.size]).all(); pos += fin.size
+    witness = whole[pos]; pos += 1
+    state = ch.compact()                              # nothing pending after the final polynomial's last full block? compact is exact either way
+    # replay the transcript tail on the oracle's challenger to get the query indices (same transcript as the whole proof)
+    och = orc.Challenger(); och.observe(seed); och.get(2)
+    p2 = 1
+    for l in range(nl):
+        och.observe(whole[p2:p2 + capw]); och.get(2); p2 += capw
+    och.observe(fin); och.observe(np.array([witness], dtype=np.uint64)); och.get(1)
+    L = 1 << (log_n + cfg.rate_bits)
+    idx = [int(x) % L for x in och.get(cfg.num_query_rounds)]
+    per = (whole.size - pos) // cfg.num_query_rounds
+    for q, x in enumerate(idx[:10]):
+        got = fc.query(gb, x)
+        assert got.size == per and (got == whole[pos + q * per: pos + (q + 1) * per]).all(), q
+    with pytest.raises(zk.ZkError):
+        fc.query(gb, L)                                # outside the domain
+    fc.free()
+    for b in gb:
+        b.free()

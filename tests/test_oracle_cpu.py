@@ -185,3 +185,29 @@ def test_fri_schedule():
     exp = {9: [4], 12: [4, 4], 14: [4, 4], 15: [4, 4, 4], 17: [4, 4, 4], 20: [4, 4, 4, 4], 23: [4, 4, 4, 4, 4]}
     for k, v in exp.items():
         assert pyspec.fri_reduction_arity_bits(k) == v
+
+
+@pytest.mark.parametrize("log_n,n_cols,n_helpers", [(4, 3, 0), (5, 6, 2), (6, 4, 1)])
+def test_c_oracle_whole_proof_equals_the_pure_python_restatement(orc, log_n, n_cols, n_helpers):
+    """oracle/stark.c (C) and oracle/pyspec.py::prove_tables (plain Python, written separately from SURVEY.md A7/A8) produce the
+    same proof words for the same unit: a second restatement of the whole STARK + FRI transcript (quotient emission order, opening
+    order, ReducingFactor bookkeeping, divide_by_linear, fold, PoW position, query layout).  Reduced FRI parameters keep the
+    pure-Python prover within seconds (2^6 rows has one arity-16 reduction layer); parity with upstream stays unpinned."""
+    import pyspec
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import air
+    from eth_tx_proof_amd._abi import StarkConfig
+    cfg = StarkConfig(100, 2, 1, 2, 3, 4, 5, 5)          # cap_height 2, PoW 3 bits, 5 query rounds
+    prog = air.cpu_like_air(n_cols, n_helpers)
+    tr, pub = orc.synth_trace(n_cols, log_n, 77 + log_n)
+    rc, ref = orc.prove(cfg, [(prog, log_n, tr, pub)])
+    assert rc == 0
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], ref) == 0
+    pcfg = dict(num_challenges=2, rate_bits=1, cap_height=2, proof_of_work_bits=3, fri_arity_bits=4, fri_final_poly_bits=5, num_query_rounds=5)
+    table = dict(log_n=log_n, trace=[[int(x) for x in c] for c in tr], pub=[int(x) for x in pub],
+                 instrs=[(i.op, i.dst, i.a, i.b) for i in prog._instrs[:prog.n_instrs]], constants=[int(x) for x in prog._constants],
+                 n_regs=prog.air.n_regs, helpers=[(h.a0, h.b0, h.a1, h.b1) for h in prog._helpers[:prog.n_helpers]])
+    got = pyspec.prove_tables(pcfg, [table])
+    assert len(got) == ref.size
+    diff = [i for i, (a, b) in enumerate(zip(got, ref)) if a != int(b)]
+    assert not diff, "first differing word %d of %d" % (diff[0], len(got))
