@@ -288,6 +288,13 @@ def main():
             h[...] = ctxs[s].download(traces[s].data_ptr(), (C, n))
             hosts.append(h)
         k = max(2, 2 * args.steps)
+        # what the link gives on this box: one unit's trace, pinned -> device, alone on an idle GPU (the same four-part upload)
+        fence()
+        t0 = time.perf_counter()
+        d0 = zl.trace_upload_async(ctxs[0], hosts[0])
+        ctxs[0].dev_free(d0)                     # waits (on the device) for the upload; the stream sync below waits for that
+        ctxs[0].synchronize()
+        h2d_gbps = 8 * C * n / (time.perf_counter() - t0) / 1e9
 
         def stream_units(s):
             try:
@@ -313,6 +320,7 @@ def main():
             if errors:
                 raise errors[0]
         pcie = {"value": k * args.inflight / dt_h, "unit": "proofs/s", "units": k * args.inflight,
+                "h2d_GBps_one_trace_alone": round(h2d_gbps, 1), "link_bound_proofs_per_s": round(h2d_gbps * 1e9 / (8 * C * n), 1),
                 "note": "traces in pinned host memory (%d MB per unit); each worker uploads unit k+1 on its copy stream while unit k is "
                         "proved (zk_trace_upload_async), first upload of every worker included in the time" % ((8 * C * n) >> 20)}
         del hosts

@@ -26,10 +26,22 @@ class HelperDesc(C.Structure):
     _fields_ = [("a0", u32), ("b0", u32), ("a1", u32), ("b1", u32)]
 
 
+class LookupCol(C.Structure):
+    _fields_ = [("col", u32), ("filter", u32)]
+
+
+class Lookup(C.Structure):
+    _fields_ = [("n_cols", u32), ("table_col", u32), ("freq_col", u32), ("reserved", u32), ("cols", C.POINTER(LookupCol))]
+
+
+NO_FILTER = 0xFFFFFFFF
+
+
 class Air(C.Structure):
     _fields_ = [("n_trace_cols", u32), ("n_public_inputs", u32), ("n_helpers", u32), ("n_constants", u32),
                 ("n_regs", u32), ("n_instrs", u32), ("constraint_degree", u32), ("reserved", u32),
-                ("helpers", C.POINTER(HelperDesc)), ("constants", C.POINTER(u64)), ("instrs", C.POINTER(Instr))]
+                ("helpers", C.POINTER(HelperDesc)), ("constants", C.POINTER(u64)), ("instrs", C.POINTER(Instr)),
+                ("lookup", C.POINTER(Lookup))]
 
 
 class StarkConfig(C.Structure):

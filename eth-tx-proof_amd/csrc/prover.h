@@ -9,7 +9,7 @@ struct DevAir {
     zk_instr *d_instrs;
     u64 *d_constants;
     zk_helper_desc *d_helpers;
-    u32 n_aux(u32 nch) const { return host->n_helpers ? nch * (host->n_helpers + 1) : 0; }
+    u32 n_aux(u32 nch) const { return zk_air_n_aux(host, nch); }
 };
 
 // prover_aux.hip

@@ -8,7 +8,7 @@
 #include "zk_internal.h"
 #include "prover.h"
 
-static u32 n_aux_of(const zk_air *air, u32 nch) { return air->n_helpers ? nch * (air->n_helpers + 1) : 0; }
+static u32 n_aux_of(const zk_air *air, u32 nch) { return zk_air_n_aux(air, nch); }
 
 extern "C" {
 
@@ -18,6 +18,15 @@ int32_t zk_air_validate(const zk_air *air, uint32_t nch) {
         air->n_instrs > (1u << 24) || air->n_constants > (1u << 24) || air->n_public_inputs > (1u << 24))
         return ZK_ERR_INVALID_ARG;
     if ((air->n_instrs && !air->instrs) || (air->n_constants && !air->constants) || (air->n_helpers && !air->helpers)) return ZK_ERR_INVALID_ARG;
+    if (air->lookup) {
+        // a lookup argument rides in front of the CTL-shaped columns and needs them present (every zkEVM table with lookups has
+        // CTLs too; the Z(1) opening batch and the proof layout key on the CTL columns)
+        const zk_lookup *lk = air->lookup;
+        if (lk->n_cols == 0 || lk->n_cols > (1u << 16) || !lk->cols || air->n_helpers == 0) return ZK_ERR_INVALID_ARG;
+        if (lk->table_col >= air->n_trace_cols || lk->freq_col >= air->n_trace_cols) return ZK_ERR_INVALID_ARG;
+        for (u32 i = 0; i < lk->n_cols; i++)
+            if (lk->cols[i].col >= air->n_trace_cols || (lk->cols[i].filter != ZK_NO_FILTER && lk->cols[i].filter >= air->n_trace_cols)) return ZK_ERR_INVALID_ARG;
+    }
     const u32 C = air->n_trace_cols, A = n_aux_of(air, nch);
     for (u32 m = 0; m < air->n_helpers; m++) {
         const zk_helper_desc &h = air->helpers[m];

@@ -100,11 +100,89 @@ __global__ __launch_bounds__(256) void scan_final_kernel(const u64 *rowsum, size
     for (u32 i = threadIdx.x; i < SCAN_BLOCK; i += 256) { size_t r = b * SCAN_BLOCK + i; if (r < n) Z[(size_t)j * n + r] = sh[i]; }
 }
 
+// ---- logUp lookup argument inside a table (starky::lookup::lookup_helper_columns)
+// helper_b = sum over a batch of two looked columns of filter / (f + beta); delta = sum_b helper_b - m / (t + beta).  One thread = one
+// row and challenge; the reciprocals of a row (two per helper + the table's) are batched four helpers at a time.
+struct LookupParams { const zk_lookup_col *cols; u32 n_cols, table_col, freq_col, LH; };
+__global__ __launch_bounds__(256) void lookup_helpers_kernel(const u64 *__restrict__ trace, size_t n, LookupParams lk, const u64 *__restrict__ chal,
+                                                            u64 *__restrict__ aux, u64 *__restrict__ rowdelta, u64 *err) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 j = blockIdx.y;
+    if (r >= n) return;
+    const u64 beta = chal[2 * j];
+    u64 *base = aux + (size_t)j * (lk.LH + 1) * n;
+    u64 total = 0;
+    for (u32 b0 = 0; b0 < lk.LH; b0 += 4) {
+        u64 num[4], den[4], pre[4];
+        u64 acc = 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            num[k] = 0; den[k] = 1;
+            const u32 b = b0 + k;
+            if (b < lk.LH) {
+                const zk_lookup_col c0 = lk.cols[2 * b];
+                const u64 d0 = gl_add(trace[(size_t)c0.col * n + r], beta);
+                const u64 f0 = c0.filter == ZK_NO_FILTER ? 1 : gl_canon(trace[(size_t)c0.filter * n + r]);
+                if (2 * b + 1 < lk.n_cols) {
+                    const zk_lookup_col c1 = lk.cols[2 * b + 1];
+                    const u64 d1 = gl_add(trace[(size_t)c1.col * n + r], beta);
+                    const u64 f1 = c1.filter == ZK_NO_FILTER ? 1 : gl_canon(trace[(size_t)c1.filter * n + r]);
+                    num[k] = gl_add(gl_mul(f0, d1), gl_mul(f1, d0)); den[k] = gl_mul(d0, d1);
+                } else { num[k] = f0; den[k] = d0; }
+            }
+            pre[k] = acc;
+            acc = gl_mul(acc, den[k]);
+        }
+        if (acc == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_ZERO_INVERSE);
+        u64 inv = gl_inv_dev(acc);
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const u64 dinv = gl_mul(inv, pre[k]);
+            inv = gl_mul(inv, den[k]);
+            if (b0 + k < lk.LH) { const u64 h = gl_mul(num[k], dinv); base[(size_t)(b0 + k) * n + r] = h; total = gl_add(total, h); }
+        }
+    }
+    const u64 dt = gl_add(trace[(size_t)lk.table_col * n + r], beta);
+    if (dt == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_ZERO_INVERSE);
+    rowdelta[(size_t)j * n + r] = gl_sub(total, gl_mul(gl_canon(trace[(size_t)lk.freq_col * n + r]), gl_inv_dev(dt)));
+}
+// forward exclusive prefix sum from the inclusive suffix sums S: Z[r] = sum_{s < r} delta[s] = S[0] - S[r]
+__global__ __launch_bounds__(256) void lookup_prefix_from_suffix_kernel(const u64 *S, size_t n, u32 LH, u64 *aux) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 j = blockIdx.y;
+    if (r >= n) return;
+    aux[((size_t)j * (LH + 1) + LH) * n + r] = gl_sub(S[(size_t)j * n], S[(size_t)j * n + r]);
+}
+
+static int32_t lookup_columns_dev(zk_ctx *ctx, const zk_lookup *lk, u32 nch, const u64 *d_chal, const u64 *d_trace, size_t n, u64 *d_aux) {
+    const u32 LH = (lk->n_cols + 1) / 2;
+    ZkOwned own(ctx);
+    zk_lookup_col *d_cols = (zk_lookup_col *)own.get((size_t)lk->n_cols * sizeof(zk_lookup_col));
+    u64 *rowdelta = (u64 *)own.get(n * nch * sizeof(u64)), *S = (u64 *)own.get(n * nch * sizeof(u64));
+    const u32 nb = (u32)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    u64 *blocksum = (u64 *)own.get((size_t)nb * nch * sizeof(u64));
+    if (!d_cols || !rowdelta || !S || !blocksum) return ctx->fail(ZK_ERR_OOM, "lookup columns: out of device memory");
+    int32_t rc = ctx->upload_small(d_cols, lk->cols, (size_t)lk->n_cols * sizeof(zk_lookup_col));
+    if (rc) return rc;
+    LookupParams p = {d_cols, lk->n_cols, lk->table_col, lk->freq_col, LH};
+    ZK_LAUNCH(ctx, "lookup_helpers", lookup_helpers_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, d_trace, n, p, d_chal, d_aux, rowdelta, ctx->d_err);
+    ZK_LAUNCH(ctx, "aux_scan_sums", scan_block_sums_kernel, dim3(nb, nch), dim3(256), 0, (const u64 *)rowdelta, n, blocksum);
+    ZK_LAUNCH(ctx, "aux_scan_suffix", scan_block_suffix_kernel, dim3(nch), dim3(64), 0, blocksum, nb);
+    ZK_LAUNCH(ctx, "aux_scan_final", scan_final_kernel, dim3(nb, nch), dim3(256), 0, (const u64 *)rowdelta, n, (const u64 *)blocksum, S);
+    ZK_LAUNCH(ctx, "lookup_prefix", lookup_prefix_from_suffix_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, (const u64 *)S, n, LH, d_aux);
+    return ZK_OK;
+}
+
 int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc *d_helpers, u32 nch, const u64 *d_chal,
                            const u64 *d_trace, u32 log_n, u64 *d_aux) {
     u32 H = air->n_helpers;
-    if (!H) return ZK_OK;
     size_t n = (size_t)1 << log_n;
+    if (air->lookup && air->lookup->n_cols) {        // lookup columns first, the CTL-shaped ones behind them (upstream's order)
+        int32_t rc = lookup_columns_dev(ctx, air->lookup, nch, d_chal, d_trace, n, d_aux);
+        if (rc) return rc;
+        d_aux += (size_t)nch * ((air->lookup->n_cols + 1) / 2 + 1) * n;
+    }
+    if (!H) return ZK_OK;
     u64 *rowsum = (u64 *)ctx->alloc(n * nch * sizeof(u64));
     u32 nb = (u32)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     u64 *blocksum = (u64 *)ctx->alloc((size_t)nb * nch * sizeof(u64));

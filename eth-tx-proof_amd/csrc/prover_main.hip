@@ -46,7 +46,7 @@ static void scratch_probe(zk_ctx *ctx, u64 *d_sink) {
 
 struct TableLayout { size_t base, o_trace_cap, o_aux_cap, o_quot_cap; FriLayout fri; size_t end; };
 
-static u32 n_aux_cols(const zk_air *air, u32 nch) { return air->n_helpers ? nch * (air->n_helpers + 1) : 0; }
+static u32 n_aux_cols(const zk_air *air, u32 nch) { return zk_air_n_aux(air, nch); }
 
 static TableLayout table_layout(const zk_stark_config &cfg, const zk_table &t, size_t base) {
     TableLayout y = {};

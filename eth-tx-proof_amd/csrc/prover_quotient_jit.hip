@@ -147,7 +147,7 @@ extern "C" int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_cha
                                              size_t *len, uint64_t *key_hash) {
     if (!air || !len || !key_hash) return ZK_ERR_INVALID_ARG;
     if (zk_air_validate(air, num_challenges) != ZK_OK) return ZK_ERR_INVALID_ARG;      // the generator indexes by operand
-    const u32 A = air->n_helpers ? num_challenges * (air->n_helpers + 1) : 0;
+    const u32 A = zk_air_n_aux(air, num_challenges);
     const u64 h = fnv1a(air_key(air, air->n_trace_cols, A, num_challenges, rate_bits));
     char name[64]; snprintf(name, sizeof name, "quotient_aot_%016llx", (unsigned long long)h);
     std::string src = generate(air, air->n_trace_cols, A, num_challenges, rate_bits, name, false);
@@ -209,7 +209,7 @@ extern "C" int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *c
         if (zk_air_validate(air, cfg->num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "prover_state_prepare: malformed AIR");
         const size_t L = (size_t)1 << (tables[t].log_n + cfg->rate_bits);
         if (!zk_quotient_jit_enabled(ctx, L)) continue;
-        const u32 nch = cfg->num_challenges, A = air->n_helpers ? nch * (air->n_helpers + 1) : 0;
+        const u32 nch = cfg->num_challenges, A = zk_air_n_aux(air, nch);
         if (ctx->quotient_aot && zk_quotient_aot_lookup(fnv1a(air_key(air, air->n_trace_cols, A, nch, cfg->rate_bits)))) continue;   // built with the library
         JitKernel k;
         int32_t rc = jit_get(ctx, air, air->n_trace_cols, A, nch, cfg->rate_bits, true, k);

@@ -174,10 +174,26 @@ typedef struct { uint32_t op, dst, a, b; } zk_instr;
  *   Z[row] = sum_{s >= row} sum_m h_m[s].                                                            */
 typedef struct { uint32_t a0, b0, a1, b1; } zk_helper_desc;
 
+/* A logUp lookup argument inside one table (starky::lookup::{Lookup, lookup_helper_columns}): looked columns f_i, each
+ * with an optional 0/1 filter column, are checked against a table column t with a multiplicity column m.  For every challenge set j
+ * (challenge beta_j) the auxiliary columns are, in upstream's order and BEFORE the CTL-shaped ones:
+ *   helper_b[row] = sum over the batch b of (constraint_degree - 1 = 2) looked columns of  filter_i[row] / (f_i[row] + beta_j)
+ *   Z[0] = 0,  Z[r+1] = Z[r] + sum_b helper_b[r] - m[r] / (t[r] + beta_j)          (forward prefix sum; it closes, Z[n] = Z[0], iff the
+ *                                                                                   multiset of looked values is the table's with m)
+ * i.e. ceil(n_cols / 2) + 1 columns per challenge: [helpers .., Z] of challenge 0, then of challenge 1, ...                      */
+#define ZK_NO_FILTER 0xFFFFFFFFu
+typedef struct { uint32_t col, filter; } zk_lookup_col;     /* trace column looked up; filter trace column or ZK_NO_FILTER (constant 1) */
+typedef struct {
+    uint32_t n_cols;                 /* looked columns */
+    uint32_t table_col, freq_col;    /* t and m: trace columns */
+    uint32_t reserved;
+    const zk_lookup_col *cols;
+} zk_lookup;
+
 typedef struct {
     uint32_t n_trace_cols;
     uint32_t n_public_inputs;
-    uint32_t n_helpers;        /* H; auxiliary columns = num_challenges * (H + 1), or 0 when H == 0 */
+    uint32_t n_helpers;        /* H; CTL-shaped auxiliary columns = num_challenges * (H + 1), or 0 when H == 0 */
     uint32_t n_constants;
     uint32_t n_regs;
     uint32_t n_instrs;
@@ -186,7 +202,14 @@ typedef struct {
     const zk_helper_desc *helpers;
     const uint64_t *constants;
     const zk_instr *instrs;
+    const zk_lookup *lookup;   /* optional (NULL: none): adds num_challenges * (ceil(lookup->n_cols / 2) + 1) auxiliary columns in front */
 } zk_air;
+/* number of auxiliary columns of an AIR: lookup columns first, CTL-shaped columns last */
+static inline uint32_t zk_air_n_aux(const zk_air *air, uint32_t num_challenges) {
+    uint32_t a = air->n_helpers ? num_challenges * (air->n_helpers + 1) : 0;
+    if (air->lookup && air->lookup->n_cols) a += num_challenges * ((air->lookup->n_cols + 1) / 2 + 1);
+    return a;
+}
 
 /* Structural check of a constraint program: every opcode known, destinations are registers below n_regs, LOCAL/NEXT indices
  * below n_trace_cols + auxiliary columns, CONST / PUBLIC / CHALLENGE indices inside their arrays (2 * num_challenges challenge

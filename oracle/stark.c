@@ -50,13 +50,49 @@ void orc_synth_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, uint64_t *t
 }
 
 /* ------------------------------------------------------------ auxiliary columns (starky::lookup / CTL partial_sums, A9) */
-static uint32_t n_aux_cols(const zk_air *air, uint32_t num_challenges) { return air->n_helpers ? num_challenges * (air->n_helpers + 1) : 0; }
+static uint32_t n_aux_cols(const zk_air *air, uint32_t num_challenges) { return zk_air_n_aux(air, num_challenges); }
+
+/* starky::lookup::lookup_helper_columns (A9): per challenge [helper_b .., Z];  helper_b = sum over a batch of two looked columns of
+ * filter / (f + beta);  Z[0] = 0, Z[r+1] = Z[r] + sum_b helper_b[r] - m[r] / (t[r] + beta) */
+static int lookup_columns(const zk_lookup *lk, uint32_t nch, const uint64_t *ch, const uint64_t *trace, size_t n, uint64_t *aux) {
+    uint32_t LH = (lk->n_cols + 1) / 2;
+    int bad = 0;
+    for (uint32_t j = 0; j < nch; j++) {
+        uint64_t beta = ch[2 * j];
+        uint64_t *base = aux + (size_t)j * (LH + 1) * n, *Z = base + (size_t)LH * n;
+        for (uint32_t b = 0; b < LH; b++)
+            for (size_t r = 0; r < n; r++) {
+                uint64_t h = 0;
+                for (uint32_t i = 2 * b; i < 2 * b + 2 && i < lk->n_cols; i++) {
+                    uint64_t d = gl_add(trace[(size_t)lk->cols[i].col * n + r], beta);
+                    if (d == 0) bad = 1;
+                    uint64_t f = lk->cols[i].filter == ZK_NO_FILTER ? 1 : gl_canon(trace[(size_t)lk->cols[i].filter * n + r]);
+                    h = gl_add(h, gl_mul(f, gl_inv(d)));
+                }
+                base[(size_t)b * n + r] = h;
+            }
+        uint64_t run = 0;
+        for (size_t r = 0; r < n; r++) {
+            Z[r] = run;
+            uint64_t d = gl_add(trace[(size_t)lk->table_col * n + r], beta);
+            if (d == 0) bad = 1;
+            uint64_t delta = gl_sub(0, gl_mul(gl_canon(trace[(size_t)lk->freq_col * n + r]), gl_inv(d)));
+            for (uint32_t b = 0; b < LH; b++) delta = gl_add(delta, base[(size_t)b * n + r]);
+            run = gl_add(run, delta);
+        }
+    }
+    return bad;
+}
 
 int32_t orc_aux_columns(const zk_air *air, uint32_t nch, const uint64_t *ch, const uint64_t *trace, uint32_t log_n, uint64_t *aux) {
     size_t n = (size_t)1 << log_n;
     uint32_t H = air->n_helpers;
-    if (!H) return ZK_OK;
     int bad = 0;
+    if (air->lookup && air->lookup->n_cols) {
+        bad |= lookup_columns(air->lookup, nch, ch, trace, n, aux);
+        aux += (size_t)nch * ((air->lookup->n_cols + 1) / 2 + 1) * n;         /* the CTL-shaped columns follow */
+    }
+    if (!H) return bad ? ZK_ERR_ZERO_INVERSE : ZK_OK;
     for (uint32_t j = 0; j < nch; j++) {
         uint64_t beta = ch[2 * j], gamma = ch[2 * j + 1];
 #pragma omp parallel for schedule(dynamic)

@@ -73,7 +73,7 @@ int32_t orc_verify(const zk_stark_config *cfg, uint32_t nt, const orc_table *tab
         for (uint32_t t = 0; t < nt; t++) {
             tbl_pos[t] = s.pos;
             uint32_t log_n = (uint32_t)r1(&s), C = (uint32_t)r1(&s), A = (uint32_t)r1(&s);
-            if (s.bad || log_n != tables[t].log_n || C != tables[t].air->n_trace_cols || A != (tables[t].air->n_helpers ? nch * (tables[t].air->n_helpers + 1) : 0)) { free(tbl_pos); return 102; }
+            if (s.bad || log_n != tables[t].log_n || C != tables[t].air->n_trace_cols || A != zk_air_n_aux(tables[t].air, nch)) { free(tbl_pos); return 102; }
             const uint64_t *cap = rn(&s, capw);
             if (!cap || !canon_all(cap, capw)) { free(tbl_pos); return 103; }
             orc_challenger_observe(&ch, cap, capw);

@@ -306,3 +306,23 @@ def test_host_resident_traces_pinned_pageable_and_prefetched_give_the_same_proof
         del pinned
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("n_looked,filtered,log_n", [(5, (1, 3), 7), (4, (), 10), (1, (0,), 6), (7, (0, 2, 6), 13)])
+def test_lookup_argument_columns_and_proof_bit_exact(ctx, zk, orc, n_looked, filtered, log_n):
+    """starky::lookup on the GPU (SURVEY.md A9): helper columns with filters (batches of two, batched inversion), the forward
+    running sum with the multiplicity column, in front of the CTL-shaped columns: zk_aux_columns == the oracle's, and the whole
+    unit proof (interpreter and, at 2^13 rows, the compiled constraint kernel path) equals the oracle's word for word."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog, tr, pub = air.lookup_air(n_looked, filtered, log_n=log_n, seed=log_n)
+    ch = np.array([5, 6, 7, 8], dtype=np.uint64)
+    rc, ref_aux = orc.aux_columns(prog, ch, tr)
+    assert rc == 0
+    assert (zk.aux_columns(ctx, prog, ch, tr) == ref_aux).all()
+    proof = zk.prove_tables(ctx, cfg, [(prog, log_n, tr, pub)])
+    rc, ref = orc.prove(cfg, [(prog, log_n, tr, pub)])
+    assert rc == 0 and proof.size == ref.size and (proof == ref).all()
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
+    bad = tr.copy(); bad[1, 3] += np.uint64(1)
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], zk.prove_tables(ctx, cfg, [(prog, log_n, bad, pub)])) != 0
