@@ -326,3 +326,25 @@ def test_lookup_argument_columns_and_proof_bit_exact(ctx, zk, orc, n_looked, fil
     assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
     bad = tr.copy(); bad[1, 3] += np.uint64(1)
     assert orc.verify(cfg, [(prog, log_n, None, pub)], zk.prove_tables(ctx, cfg, [(prog, log_n, bad, pub)])) != 0
+
+
+def test_cfg4_small_tables_at_their_real_sizes_bit_exact(ctx, zk, orc):
+    """BASELINE configs[3]: BytePacking (71 x 2^9), Cpu (93 x 2^12), KeccakSponge (430 x 2^9) and Logic (523 x 2^12) at their real
+    sizes and widths, Arithmetic / Keccak / Memory at reduced heights (the oracle's prover would take minutes at 2^15 / 2^14 x 2431 /
+    2^17), all seven on one challenger in table order: the GPU proof equals the oracle's word for word.  (The full shape is
+    verifier-checked in test_cfg4_seven_table_shapes.)"""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    shapes = list(zip(air.ZKEVM_TABLE_WIDTHS, (11, 9, 12, 8, 9, 12, 12)))        # real: 15, 9, 12, 14, 9, 12, 17
+    items = []
+    for t, (w, lg) in enumerate(shapes):
+        prog = air.cpu_like_air(w, min(19, w // 4))
+        tr, pub = orc.synth_trace(w, lg, 0x5EED0000 + 1000 * t)
+        items.append((prog, lg, tr, pub))
+    proof = zk.prove_tables(ctx, cfg, items)
+    rc, ref = orc.prove(cfg, items)
+    assert rc == 0 and proof.size == ref.size
+    if not (proof == ref).all():
+        bad = np.nonzero(proof != ref)[0]
+        pytest.fail("first differing word %d of %d" % (bad[0], proof.size))
+    assert orc.verify(cfg, [(p, lg, None, pub) for p, lg, _, pub in items], proof) == 0
