@@ -211,3 +211,15 @@ def test_c_oracle_whole_proof_equals_the_pure_python_restatement(orc, log_n, n_c
     assert len(got) == ref.size
     diff = [i for i, (a, b) in enumerate(zip(got, ref)) if a != int(b)]
     assert not diff, "first differing word %d of %d" % (diff[0], len(got))
+
+
+def test_oracle_proofs_match_the_committed_digests(orc):
+    """tests/golden/proof_digests.json (tools/gen_golden_proofs.py): DERIVED regression pins of the oracle's own proofs -- STARK
+    unit proofs, a proof with a logUp lookup argument, a Plonk-shaped proof -- so that a change of the oracle, of a convention or of
+    the proof layout cannot pass unnoticed.  Not upstream vectors: parity stays unpinned."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden_proofs", os.path.join(os.path.dirname(GOLD), "..", "tools", "gen_golden_proofs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(GOLD, "proof_digests.json")))
+    assert mod.digests() == want
