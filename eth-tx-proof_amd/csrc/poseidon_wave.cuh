@@ -1,0 +1,112 @@
+// Wave-wide Poseidon permutation: ONE permutation per 64-lane wave, built for latency.  Same function as psd::permute
+// (poseidon.cuh; plonky2 0.2.2 hash/poseidon.rs `Poseidon::poseidon`).  It is what a serial sponge needs -- the
+// Fiat-Shamir transcript absorbing thousands of opening values is a chain of permutations nothing can run beside -- and what the
+// top levels of a Merkle tree need once a level has fewer nodes than the chip has SIMDs.
+//
+// A single wave issues one instruction at a time, so latency = instruction count.  Against the 16-lane version
+// (poseidon_coop.cuh, ~6100 instructions per permutation) this one runs ~2700:
+//   * full rounds: state word l in lane l; the MDS row of lane l sits in 12 registers and the twelve state words arrive as
+//     wave-uniform SGPR pairs (v_readlane) -- 24 v_mad_u64_u32 per layer, no LDS-path shuffles, no index arithmetic;
+//   * partial rounds: the 22 rounds are one serial chain  u_q = sbox(x0_q) + K_q  with every other word eliminated
+//     (tools/gen_constants.py derive_wave): lane k accumulates "x0 before round k", lanes 32..43 the final state, and a round is
+//     readlane(x0) -> s-box on the uniform value -> ONE multiply-add per lane against the lane's coefficient of u_q.
+//     No cross-lane reduction at all (the 16-lane version spends 4 shuffle+add stages per round on its dot product).
+// Tables: PSD_WV_INIT[12][64], PSD_WV_CHAIN[22][64], PSD_WV_MDS[12][64] (23 KB), staged in LDS by the caller (fill()).
+#pragma once
+#include "poseidon.cuh"
+
+namespace psdw {
+
+constexpr int TAB_WORDS = (12 + 22 + 12) * 64;      // 23 KB
+
+// all threads of the block copy the two tables into `lds` (TAB_WORDS u64); caller synchronises afterwards
+__device__ __forceinline__ void fill(u64 *lds) {
+    for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lds[i] = PSD_WV_INIT[i];
+    for (int i = threadIdx.x; i < 22 * 64; i += blockDim.x) lds[12 * 64 + i] = PSD_WV_CHAIN[i];
+    for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lds[34 * 64 + i] = PSD_WV_MDS[i];
+}
+
+__device__ __forceinline__ u64 rdlane64(u64 v, int l) {
+    u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+// EXACT = false: the products skip their one-in-2^32 borrow repair and flag it in pc.fl instead (poseidon.cuh psd::core);
+// permute() below redoes the permutation with every repair in place when the flag is up -- results identical either way.
+template <bool EXACT> struct perm {
+    u32 m[12];              // MDS coefficients of this lane's output row: out_l = sum_i m[i] * s_i
+    int lane, lc;
+    const u64 *tab;         // LDS copy of the tables
+    psd::core<EXACT> pc;
+
+    __device__ __forceinline__ void init(int lane_, const u64 *lds_tab) {
+        lane = lane_; lc = lane < 12 ? lane : 0; tab = lds_tab; pc.fl = 0;
+        // coefficient of s_i in out_l: CIRC[(i - l) mod 12], + 8 on the diagonal of row 0; rows of idle lanes are zero
+#pragma unroll
+        for (int i = 0; i < 12; i++) m[i] = (u32)tab[34 * 64 + 64 * i + lane];
+    }
+
+    // four full rounds starting at `round`; weak in (lanes 0..11), weak out, idle lanes come out 0
+    __device__ __forceinline__ u64 full_rounds(u64 s, int round) {
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) {
+            s = pc.sbox(psd::wadd_c(s, PSD_RC[12 * (round + r) + lc]));
+            const u32 lo = (u32)s, hi = (u32)(s >> 32);
+            u64 al = 0, ah = 0;
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const u32 xl = (u32)__builtin_amdgcn_readlane((int)lo, i), xh = (u32)__builtin_amdgcn_readlane((int)hi, i);
+                al += (u64)xl * m[i]; ah += (u64)xh * m[i];
+            }
+            // al + ah*2^32, both < 2^41: low64 + high*2^64 with high < 2^9 -> low + high*eps
+            u32 th, cy;
+            th = __builtin_addc((u32)(al >> 32), (u32)ah, 0u, &cy);
+            const u32 high = (u32)(ah >> 32) + cy;
+            s = gl_mad_eps(high, ((u64)th << 32) | (u32)al);
+        }
+        return s;
+    }
+
+    // s: state word `lane` for lane < 12 (any 64-bit representative), ignored elsewhere.  Returns the permuted word, canonical, in
+    // lanes 0..11 and 0 in the others.  Must be called by all 64 lanes.
+    __device__ __forceinline__ u64 run(u64 s) {
+        s = full_rounds(s, 0);
+        // ---- 22 partial rounds
+        const u64 z = psd::wadd_c(s, PSD_PR_FIRST[lc]);
+        u64 acc;
+        {
+            psd::acc3 a; a.init();
+#pragma unroll
+            for (int i = 0; i < 12; i++) a.mac_s(rdlane64(z, i), tab[64 * i + lane]);
+            acc = pc.reduce(a);
+        }
+        const u64 *ch = tab + 12 * 64 + lane;
+        u64 cnext = ch[0];
+#pragma unroll 2
+        for (int q = 0; q < 22; q++) {
+            const u64 c = cnext;
+            cnext = ch[64 * (q < 21 ? q + 1 : 21)];
+            const u64 x0 = rdlane64(acc, q);
+            const u64 u = psd::wadd_c(pc.sbox(x0), PSD_PR_K[q]);
+            acc = pc.mul_add(c, u, acc);
+        }
+        // final state sits in lanes 32..43
+        {
+            u32 lo = (u32)acc, hi = (u32)(acc >> 32);
+            lo = __shfl(lo, (lane + 32) & 63, 64); hi = __shfl(hi, (lane + 32) & 63, 64);
+            s = ((u64)hi << 32) | lo;
+        }
+        s = full_rounds(s, 26);
+        return lane < 12 ? gl_canon(s) : 0;
+    }
+};
+
+// s: state word `lane` for lane < 12, any representative; all 64 lanes must call.  `tab` = LDS tables (fill()).
+__device__ __forceinline__ u64 permute(u64 s, int lane, const u64 *tab) {
+    perm<false> pf; pf.init(lane, tab);
+    u64 r = pf.run(s);
+    if (pf.pc.fl) { perm<true> pe; pe.init(lane, tab); r = pe.run(s); }
+    return r;
+}
+
+}  // namespace psdw

@@ -6,30 +6,41 @@
 // never cross PCIe while a proof is being produced; every consumer kernel reads its challenges from device memory.
 #include "zk_internal.h"
 #include "poseidon_coop.cuh"
+#include "poseidon_wave.cuh"
 #include "transcript.h"
 
 // The kernel runs as ONE wave.  The challenger is staged in LDS; every lane executes the (uniform) control flow, lane 0
-// does the bookkeeping writes, and the permutation is the lane-cooperative one (poseidon_coop.cuh): state element l in
-// lane l of each 16-lane group (the four groups compute the same permutation).
-__device__ void ch_duplex(DevChallenger *c) {
-    const int lane = threadIdx.x, l = lane & 15, gb = lane & ~15;
+// does the bookkeeping writes, and the permutation is the wave-wide one (poseidon_wave.cuh): state element l in lane l, the
+// whole wave working on the one permutation -- a sponge is a serial chain, so the latency of ONE permutation is all that counts.
+// (ZK_TRANSCRIPT_COOP=1 selects the older 16-lane version, poseidon_coop.cuh, for comparison.)
+// One copy of the permutation code in the kernel (every call site jumps here): the instruction stream of a permutation is what
+// the single wave waits for, so it should stay resident in the instruction cache.
+struct ChPerm {
+    const u64 *wtab; bool wave;
+    __device__ __noinline__ u64 run(u64 s, int lane) const {
+        if (wave) return psdw::permute(s, lane, wtab);
+        return psdc::permute16(s, lane & 15, lane & ~15);
+    }
+};
+__device__ void ch_duplex(DevChallenger *c, ChPerm &P) {
+    const int lane = threadIdx.x, l = lane & 15;
     u64 s = 0;
     if (l < 12) s = c->state[l];
     if ((u32)l < c->n_in) s = c->inbuf[l];
     __syncthreads();
-    s = psdc::permute16(s, l, gb);
+    s = P.run(s, lane);
     if (lane < 12) c->state[lane] = s;
     if (lane < 8) c->outbuf[lane] = s;
     if (lane == 0) { c->n_in = 0; c->n_out = 8; }
     __syncthreads();
 }
-__device__ void ch_observe(DevChallenger *c, u64 x) {
+__device__ void ch_observe(DevChallenger *c, ChPerm &P, u64 x) {
     if (threadIdx.x == 0) { c->n_out = 0; c->inbuf[c->n_in] = gl_canon(x); c->n_in = c->n_in + 1; }
     __syncthreads();
-    if (c->n_in == 8) ch_duplex(c);
+    if (c->n_in == 8) ch_duplex(c, P);
 }
-__device__ u64 ch_get(DevChallenger *c) {
-    if (c->n_in || !c->n_out) ch_duplex(c);
+__device__ u64 ch_get(DevChallenger *c, ChPerm &P) {
+    if (c->n_in || !c->n_out) ch_duplex(c, P);
     u64 v = c->outbuf[c->n_out - 1];
     __syncthreads();
     if (threadIdx.x == 0) c->n_out = c->n_out - 1;
@@ -37,10 +48,13 @@ __device__ u64 ch_get(DevChallenger *c) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpList ops, u64 *err) {
+__global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpList ops, u64 *err, int wave) {
     __shared__ DevChallenger L;
+    __shared__ u64 wtab[psdw::TAB_WORDS];
     DevChallenger *c = &L;
     const int lane = threadIdx.x;
+    ChPerm P; P.wave = wave != 0; P.wtab = wtab;
+    if (P.wave) psdw::fill(wtab);
     {
         const u64 *src = (const u64 *)gc; u64 *dst = (u64 *)c;
         for (u32 i = lane; i < sizeof(DevChallenger) / 8; i += 64) dst[i] = src[i];
@@ -59,9 +73,9 @@ __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpLi
             // registers: one coalesced (prefetched) load and one permutation per 8 elements -- wide opening sets (thousands of
             // columns) are a serial chain of permutations, so everything else must stay off that chain
             u32 i = 0;
-            while (i < o.n && c->n_in != 0) ch_observe(c, o.src[i++]);
+            while (i < o.n && c->n_in != 0) ch_observe(c, P, o.src[i++]);
             if (i + 8 <= o.n) {
-                const int l = lane & 15, gb = lane & ~15;
+                const int l = lane & 15;
                 u64 st = l < 12 ? c->state[l] : 0;
                 u64 nxt = l < 8 ? gl_canon(o.src[i + l]) : 0;
                 while (i + 8 <= o.n) {
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpLi
                     i += 8;
                     if (i + 8 <= o.n && l < 8) nxt = gl_canon(o.src[i + l]);
                     if (l < 8) st = cur;
-                    st = psdc::permute16(st, l, gb);
+                    st = P.run(st, lane);
                     if (l >= 12) st = 0;
                 }
                 __syncthreads();
@@ -78,17 +92,17 @@ __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpLi
                 if (lane == 0) { c->n_in = 0; c->n_out = 8; }
                 __syncthreads();
             }
-            while (i < o.n) ch_observe(c, o.src[i++]);
+            while (i < o.n) ch_observe(c, P, o.src[i++]);
             break;
         }
         case TOP_OBSERVE_BASE_AS_EXT:
-            for (u32 i = 0; i < o.n; i++) { ch_observe(c, o.src[i]); ch_observe(c, 0); }
+            for (u32 i = 0; i < o.n; i++) { ch_observe(c, P, o.src[i]); ch_observe(c, P, 0); }
             break;
         case TOP_GET:
-            for (u32 i = 0; i < o.n; i++) { u64 v = ch_get(c); if (lane == 0) o.dst[i] = v; }
+            for (u32 i = 0; i < o.n; i++) { u64 v = ch_get(c, P); if (lane == 0) o.dst[i] = v; }
             break;
         case TOP_COMPACT:
-            if (c->n_in) ch_duplex(c);
+            if (c->n_in) ch_duplex(c, P);
             if (lane == 0) c->n_out = 0;
             __syncthreads();
             if (o.dst && lane < 12) o.dst[lane] = c->state[lane];
@@ -102,8 +116,8 @@ __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpLi
         case TOP_POW_FINISH: {
             u64 w = __hip_atomic_load((u64 *)&o.src[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (w == ~0ULL) { if (lane == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW); w = 0; }
-            ch_observe(c, w);
-            u64 resp = ch_get(c);
+            ch_observe(c, P, w);
+            u64 resp = ch_get(c, P);
             if (lane == 0) {
                 if ((u32)__clzll((long long)resp) < o.n) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW);
                 o.dst[0] = w;
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpLi
         }
         case TOP_GET_INDICES:
             // fri_prover_query_rounds: x_index = challenge.to_canonical_u64() as usize % lde_size (lde_size = 2^o.aux)
-            for (u32 i = 0; i < o.n; i++) { u64 v = ch_get(c); if (lane == 0) o.dst[i] = v & (((u64)1 << o.aux) - 1); }
+            for (u32 i = 0; i < o.n; i++) { u64 v = ch_get(c, P); if (lane == 0) o.dst[i] = v & (((u64)1 << o.aux) - 1); }
             break;
         }
     }
@@ -139,7 +153,8 @@ __global__ __launch_bounds__(256) void pow_grind_kernel(u64 *pow_state /* 14 wor
 }
 
 int32_t zk_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops) {
-    ZK_LAUNCH(ctx, "transcript", transcript_kernel, dim3(1), dim3(64), 0, c, ops, ctx->d_err);
+    static const int wave = []() { const char *e = getenv("ZK_TRANSCRIPT_COOP"); return (e && e[0] == '1') ? 0 : 1; }();
+    ZK_LAUNCH(ctx, "transcript", transcript_kernel, dim3(1), dim3(64), 0, c, ops, ctx->d_err, wave);
     return ZK_OK;
 }
 

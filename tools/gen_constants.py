@@ -109,6 +109,62 @@ def poseidon_sparse(state, tabs):
     return s
 
 
+def derive_wave(tabs):
+    """Tables of the wave-wide permutation (poseidon_wave.cuh): the 22 partial rounds as ONE serial chain of s-boxes with every
+    other word of the state eliminated.  With x = state after PR_FIRST/PR_INIT and u_q = sbox(x0 before round q) + K[q]:
+        x_j before round r  = x_j + sum_{q<r} W[q][j-1] u_q                                   (j >= 1)
+        x_0 before round k  = M00 u_{k-1} + <VHAT[k-1], x_1..11> + sum_{q<k-1} <VHAT[k-1], W[q]> u_q   (k >= 1)
+    Lane k (k = 0..21) accumulates x_0 before round k, lane 32 the final x_0, lane 32+j the final x_j.
+      init[i][lane]  : coefficient of z_i (z = state after the first four full rounds + PR_FIRST) in the lane's starting value
+      chain[q][lane] : coefficient of u_q in the lane's accumulator"""
+    first, init, k, vhat, wcol, m00 = tabs
+
+    def lane_of_x0(kk):
+        return kk if kk < R_P else 32
+    T_init = [[0] * 64 for _ in range(12)]
+    T_chain = [[0] * 64 for _ in range(R_P)]
+    T_init[0][0] = 1
+    for kk in range(1, R_P + 1):
+        ln = lane_of_x0(kk)
+        for i in range(1, 12):
+            T_init[i][ln] = sum(vhat[kk - 1][j] * init[j][i - 1] for j in range(11)) % P
+        for q in range(kk):
+            T_chain[q][ln] = m00 if q == kk - 1 else sum(vhat[kk - 1][j] * wcol[q][j] for j in range(11)) % P
+    for j in range(1, 12):
+        for i in range(1, 12):
+            T_init[i][32 + j] = init[j - 1][i - 1]
+        for q in range(R_P):
+            T_chain[q][32 + j] = wcol[q][j - 1]
+    return T_init, T_chain
+
+
+def poseidon_wave(state, tabs, wave):
+    """The permutation as poseidon_wave.cuh computes it (64 "lanes"); must equal S.poseidon."""
+    first, init, k, vhat, wcol, m00 = tabs
+    T_init, T_chain = wave
+    RC = S.rc()
+    s = [x % P for x in state]
+    r = 0
+    for _ in range(4):
+        s = [(s[i] + RC[12 * r + i]) % P for i in range(12)]
+        s = [pow(x, 7, P) for x in s]
+        s = S._mds(s)
+        r += 1
+    z = [(s[i] + first[i]) % P for i in range(12)]
+    acc = [sum(T_init[i][ln] * z[i] for i in range(12)) % P for ln in range(64)]
+    for q in range(R_P):
+        u = (pow(acc[q], 7, P) + k[q]) % P
+        acc = [(acc[ln] + T_chain[q][ln] * u) % P for ln in range(64)]
+    s = [acc[32 + j] for j in range(12)]
+    r += R_P
+    for _ in range(4):
+        s = [(s[i] + RC[12 * r + i]) % P for i in range(12)]
+        s = [pow(x, 7, P) for x in s]
+        s = S._mds(s)
+        r += 1
+    return s
+
+
 def c_array(name, vals, per_line=4, ctype="uint64_t", qual="static const"):
     lines = []
     for i in range(0, len(vals), per_line):
@@ -122,8 +178,10 @@ def main():
     import random
     rnd = random.Random(1)
     tests = [k[0] for k in S.KATS] + [[rnd.randrange(P) for _ in range(12)] for _ in range(8)]
+    wave = derive_wave(tabs)
     for t in tests:
         assert poseidon_sparse(t, tabs) == S.poseidon(t)
+        assert poseidon_wave(t, tabs, wave) == S.poseidon(t)
     first, init, k, vhat, wcol, m00 = tabs
     hdr = ("/* GENERATED by tools/gen_constants.py -- do not edit.\n"
            " * Poseidon-Goldilocks round constants = 360 x ChaCha8Rng::seed_from_u64(0).gen_range(0..p)\n"
@@ -153,6 +211,14 @@ def main():
                 for q in range(R_P)]
         f.write(c_array("PSD_PR_D", [x for row in dmat for x in row], per_line=11, qual="PSD_CONST"))
         f.write("#define PSD_M00 %dULL\n" % m00)
+        # wave-wide permutation (poseidon_wave.cuh): see derive_wave()
+        f.write(c_array("PSD_WV_INIT", [x for row in wave[0] for x in row], per_line=8, qual="PSD_CONST"))
+        f.write(c_array("PSD_WV_CHAIN", [x for row in wave[1] for x in row], per_line=8, qual="PSD_CONST"))
+        # MDS rows per lane: out_l = sum_i PSD_WV_MDS[i][l] * s_i (zero rows for the idle lanes l >= 12)
+        mds = [[(S.MDS_CIRC[(i - l) % 12] + (S.MDS_DIAG[0] if i == 0 and l == 0 else 0)) if l < 12 else 0 for l in range(64)] for i in range(12)]
+        Mfull = S.mds_matrix()
+        assert all(mds[i][l] == Mfull[l][i] for i in range(12) for l in range(12)) and all(S.MDS_DIAG[i] == 0 for i in range(1, 12))
+        f.write(c_array("PSD_WV_MDS", [x for row in mds for x in row], per_line=8, qual="PSD_CONST"))
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     with open(os.path.join(ROOT, "tests", "golden", "poseidon_rc.json"), "w") as f:
         json.dump({"sha256_le_u64": hashlib.sha256(b"".join(struct.pack("<Q", c) for c in RC)).hexdigest(),
