@@ -327,5 +327,10 @@ void zk_stark_config_standard_fast(zk_stark_config *c) {
     c->security_bits = 100; c->num_challenges = 2; c->rate_bits = 1; c->cap_height = 4;
     c->proof_of_work_bits = 16; c->fri_arity_bits = 4; c->fri_final_poly_bits = 5; c->num_query_rounds = 84;
 }
+void zk_stark_config_standard_recursion(zk_stark_config *c) {
+    if (!c) return;
+    c->security_bits = 100; c->num_challenges = 2; c->rate_bits = 3; c->cap_height = 4;
+    c->proof_of_work_bits = 16; c->fri_arity_bits = 4; c->fri_final_poly_bits = 5; c->num_query_rounds = 28;
+}
 
 }  // extern "C"

@@ -1,12 +1,16 @@
 // C++ host-side mirror of the reference's operator surface over the C ABI (include/zkgl.h).
 //   /root/reference/ops/src/lib.rs:16-18   fn p_state() -> &'static ProverState   (P_STATE.get().expect(..))
 //   /root/reference/ops/src/lib.rs:22-62   TxProof: Operation { execute(GenerationInputs) -> Result<AggregatableProof> }
-//   /root/reference/ops/src/lib.rs:64-82   AggProof: Monoid   { combine, empty }            (recursion: SURVEY.md 8f-2)
-//   /root/reference/ops/src/lib.rs:84-101  BlockProof: Operation                              (recursion: SURVEY.md 8f-2)
+//   /root/reference/ops/src/lib.rs:64-82   AggProof: Monoid   { combine, empty }            (zk_prove_plonk)
+//   /root/reference/ops/src/lib.rs:84-101  BlockProof: Operation                              (zk_prove_plonk)
+//   /root/reference/leader/src/prover.rs:14-43  ProverInput::prove = map(&TxProof).fold(&AggProof) -> BlockProof
 // Same names, by-value input, errors as paladin::operation::FatalError.  Header only; link libzkgl_hip.so.
+// The recursion CIRCUITS (AllRecursiveCircuits: gate sets, verifier gadgets, witness generators) live in crates absent from the
+// reference tree: they are an input here (ProverState::recursion); without them combine / execute throw FatalError.
 #pragma once
 #include <chrono>
 #include <cstdint>
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -29,18 +33,36 @@ struct AggregatableProof {
     std::vector<uint64_t> proof;       // words as documented in zkgl.h
 };
 
+struct GeneratedBlockProof { uint64_t b_height = 0; std::vector<uint64_t> intern; };     // leader/src/prover.rs:9,36-40
+
+// one Plonk proof to produce: circuit prover data (zk_plonk_setup), its config, the witness, the public inputs
+struct PlonkJob {
+    const zk_stark_config *cfg = nullptr;
+    zk_plonk_state *state = nullptr;
+    const zk_plonk_circuit *circuit = nullptr;
+    const uint64_t *wires = nullptr;
+    uint32_t wires_on_device = 0;
+    std::vector<uint64_t> public_inputs;
+};
+struct RecursionCircuits {             // supplied by the integrator; called on the worker thread with its context
+    std::function<PlonkJob(zk_ctx *, const AggregatableProof &, const AggregatableProof &)> aggregation;
+    std::function<PlonkJob(zk_ctx *, const std::vector<uint64_t> *prev, const AggregatableProof &)> block;
+};
+
 struct ProverState {                   // common::prover_state::ProverState: built once, immutable afterwards
     int device = 0;
     zk_stark_config config;
+    RecursionCircuits recursion;
 };
 inline ProverState *&p_state_slot() { static ProverState *s = nullptr; return s; }
 inline std::mutex &p_state_mutex() { static std::mutex m; return m; }
 // common/src/prover_state/mod.rs:59-95; a second call leaves the first state (worker/src/main.rs:25-27 only warns)
-inline bool set_prover_state_from_config(int device) {
+inline bool set_prover_state_from_config(int device, RecursionCircuits recursion = {}) {
     std::lock_guard<std::mutex> g(p_state_mutex());
     if (p_state_slot()) return false;
     auto *s = new ProverState();
     s->device = device;
+    s->recursion = std::move(recursion);
     zk_stark_config_standard_fast(&s->config);     // circuit.rs:200-206
     p_state_slot() = s;
     return true;
@@ -76,15 +98,57 @@ struct TxProof {
         return out;
     }
 };
+inline std::vector<uint64_t> prove_plonk_job(const char *what, const PlonkJob &job) {
+    zk_ctx *ctx = thread_ctx();
+    std::vector<uint64_t> proof(zk_plonk_proof_size_words(job.cfg, job.circuit));
+    size_t len = 0;
+    int32_t rc = zk_prove_plonk(ctx, job.cfg, job.state, job.wires, job.wires_on_device, job.public_inputs.data(),
+                                (uint32_t)job.public_inputs.size(), proof.data(), proof.size(), &len);
+    if (rc != ZK_OK) throw FatalError(std::string(what) + ": " + zk_last_error(ctx));               // lib.rs:72,96
+    proof.resize(len);
+    return proof;
+}
 struct AggProof {
-    AggregatableProof combine(const AggregatableProof &, const AggregatableProof &) {
-        throw FatalError("generate_agg_proof: the aggregation circuit is not available (SURVEY.md 8f-2, A10); zk_prove_plonk proves circuits given as data");
+    AggregatableProof combine(const AggregatableProof &a, const AggregatableProof &b) {
+        const ProverState &st = p_state();
+        if (!st.recursion.aggregation)
+            throw FatalError("generate_agg_proof: no recursion circuits in the prover state (SURVEY.md 8f-2, A10); zk_prove_plonk proves circuits given as data");
+        AggregatableProof out;
+        out.kind = AggregatableProof::Agg;
+        out.proof = prove_plonk_job("generate_agg_proof", st.recursion.aggregation(thread_ctx(), a, b));
+        return out;
     }
     AggregatableProof empty() { throw std::logic_error("empty agg proof"); }   // lib.rs:78-81 unimplemented!
 };
 struct BlockProof {
-    AggregatableProof execute(const AggregatableProof &) {
-        throw FatalError("generate_block_proof: the block circuit is not available (SURVEY.md 8f-2, A10); zk_prove_plonk proves circuits given as data");
+    const std::vector<uint64_t> *prev = nullptr;
+    GeneratedBlockProof execute(const AggregatableProof &agg) {
+        const ProverState &st = p_state();
+        if (!st.recursion.block)
+            throw FatalError("generate_block_proof: no recursion circuits in the prover state (SURVEY.md 8f-2, A10); zk_prove_plonk proves circuits given as data");
+        PlonkJob job = st.recursion.block(thread_ctx(), prev, agg);
+        GeneratedBlockProof out;
+        out.b_height = job.public_inputs.empty() ? 0 : job.public_inputs[0];
+        out.intern = prove_plonk_job("generate_block_proof", job);
+        return out;
+    }
+};
+// leader/src/prover.rs:20-43 on the calling thread: map, balanced pairwise fold (combine is associative), block proof
+struct ProverInput {
+    std::vector<GenerationInputs> proof_gen_ir;
+    GeneratedBlockProof prove(const std::vector<uint64_t> *previous = nullptr) {
+        std::vector<AggregatableProof> level;
+        for (auto &in : proof_gen_ir) level.push_back(TxProof{}.execute(in));                      // .map(&TxProof)
+        if (level.empty()) AggProof{}.empty();
+        while (level.size() > 1) {                                                                  // .fold(&AggProof)
+            std::vector<AggregatableProof> next;
+            for (size_t j = 0; j + 1 < level.size(); j += 2) next.push_back(AggProof{}.combine(level[j], level[j + 1]));
+            if (level.size() & 1) next.push_back(level.back());
+            level.swap(next);
+        }
+        if (level[0].kind != AggregatableProof::Agg) throw std::runtime_error("AggProof is is not GeneratedAggProof");   // prover.rs:41
+        BlockProof bp; bp.prev = previous;
+        return bp.execute(level[0]);                                                                // Literal(proof).map(&BlockProof)
     }
 };
 

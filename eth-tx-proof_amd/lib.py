@@ -33,10 +33,11 @@ def build(force=False, jobs=8):
 
 
 def declared_symbols():
-    """Every function name declared in include/zkgl.h."""
+    """Every exported function name declared in include/zkgl.h (static inline helpers defined in the header are not exports)."""
     txt = open(_HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", txt)))
+    inline = set(re.findall(r"static\s+inline\s+[a-z0-9_]+\s+(zk_[a-z0-9_]+)\s*\(", txt))
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", txt)) - inline)
 
 
 def lib():

@@ -3,8 +3,13 @@
   reference                                   here
   P_STATE: OnceLock<ProverState>              P_STATE / set_prover_state_from_config   (common/src/prover_state/mod.rs:31,59-95)
   TxProof: Operation  (lib.rs:22-62)          TxProof.execute(input) -> AggregatableProof.Txn
-  AggProof: Monoid    (lib.rs:64-82)          AggProof.combine / .empty  (recursion not built: SURVEY 8f-2 -> FatalError)
+  AggProof: Monoid    (lib.rs:64-82)          AggProof.combine / .empty  (zk_prove_plonk over the circuits in p_state().recursion)
   BlockProof: Operation (lib.rs:84-101)       BlockProof.execute          (same)
+
+The Plonk half: the PROVER is here (lib.prove_plonk, csrc/prover_plonk.hip); the recursion CIRCUITS (gate sets, recursive
+verifier gadgets, witness generators of AllRecursiveCircuits) live in crates absent from the reference tree, so they
+are an input: `ProverState(recursion=...)` takes an object implementing RecursionCircuits.  Without one, combine / execute raise
+FatalError as the reference does for any prover failure.
 
 `GenerationInputs` upstream is the witness of one transaction; trace generation from it is a CPU EVM interpreter that
 is out of scope, so here it carries the already generated traces of the unit's tables.
@@ -47,12 +52,32 @@ class AggregatableProof:
     public_values: list = field(default_factory=list)
 
 
-class ProverState:
-    """Per-process immutable prover state: StarkConfig + one zk_ctx per worker thread."""
+@dataclass
+class GeneratedBlockProof:
+    """proof_gen::proof_types::GeneratedBlockProof { b_height, intern } (/root/reference/leader/src/prover.rs:9,36-40)."""
+    b_height: int
+    intern: np.ndarray
 
-    def __init__(self, device=0, config=None):
+
+class RecursionCircuits:
+    """The circuits of the Plonk half as data + their witness generators (upstream: AllRecursiveCircuits inside ProverState,
+    /root/reference/common/src/prover_state/mod.rs:31-57).  Each method returns (lib.PlonkState on `ctx`, wires, public_inputs):
+    the circuit's prover data, a (num_wires, n) witness (host array or device pointer) and the public inputs of THIS proof."""
+
+    def aggregation(self, ctx, lhs: "AggregatableProof", rhs: "AggregatableProof"):
+        raise NotImplementedError
+
+    def block(self, ctx, prev: Optional[np.ndarray], agg: "AggregatableProof"):
+        raise NotImplementedError
+
+
+class ProverState:
+    """Per-process immutable prover state: StarkConfig + one zk_ctx per worker thread (+ the recursion circuits, if supplied)."""
+
+    def __init__(self, device=0, config=None, recursion: Optional[RecursionCircuits] = None):
         self.device = device
         self.config = config or standard_fast_config()
+        self.recursion = recursion
         self._tls = threading.local()
 
     def ctx(self):
@@ -61,6 +86,16 @@ class ProverState:
             c = zl.Context(self.device)
             self._tls.ctx = c
         return c
+
+    def drop_ctx(self):
+        """Close the calling thread's context (after a device error): the next ctx() call makes a fresh one."""
+        c = getattr(self._tls, "ctx", None)
+        self._tls.ctx = None
+        if c is not None:
+            try:
+                c.close()
+            except Exception:
+                pass
 
     def prepare(self, tables):
         """Build the compiled part of the prover state for these table shapes (zk_prover_state_prepare): the reference builds its
@@ -73,13 +108,13 @@ P_STATE: Optional[ProverState] = None
 _lock = threading.Lock()
 
 
-def set_prover_state_from_config(device=0, config=None):
+def set_prover_state_from_config(device=0, config=None, recursion=None):
     """Initialises the global prover state once; a second call leaves the first state in place and returns it
     (the reference only warns on double initialisation, worker/src/main.rs:25-27)."""
     global P_STATE
     with _lock:
         if P_STATE is None:
-            P_STATE = ProverState(device, config)
+            P_STATE = ProverState(device, config, recursion)
         return P_STATE
 
 
@@ -106,24 +141,38 @@ class TxProof:
         return AggregatableProof("Txn", proof, [t.public_inputs for t in input.tables])
 
 
-class AggProof:
-    """Monoid over AggregatableProof (lib.rs:67-82): Plonk recursion, not built yet."""
+def _prove_recursive(what, build):
+    st = p_state()
+    if st.recursion is None:
+        raise FatalError("%s: no recursion circuits in the prover state (SURVEY.md 8f-2, A10): pass ProverState(recursion=...); "
+                         "zk_prove_plonk proves circuits given as data" % what)
+    try:
+        state, wires, pubs = build(st.recursion, st.ctx())
+        return zl.prove_plonk(state, wires, pubs), np.asarray(pubs, dtype=np.uint64)
+    except FatalError:
+        raise
+    except Exception as e:          # .map_err(FatalError::from)?   lib.rs:72,96
+        raise FatalError("%s: %s" % (what, e)) from e
 
-    def combine(self, a, b):
-        # the Plonk PROVER of the recursion half exists (lib.prove_plonk, bit-exact against its oracle on circuits given as data);
-        # the aggregation CIRCUIT (gate set, recursive verifier gadgets, witness generator) lives in crates that are absent from the
-        # reference tree, so there is nothing honest to prove here
-        raise FatalError("generate_agg_proof: the aggregation circuit is not available (SURVEY.md 8f-2, A10); zk_prove_plonk proves "
-                         "circuits given as data")
+
+class AggProof:
+    """Monoid over AggregatableProof (lib.rs:64-82): combine = generate_agg_proof(p_state(), lhs, rhs) -> Agg."""
+
+    def combine(self, a: AggregatableProof, b: AggregatableProof) -> AggregatableProof:
+        proof, pubs = _prove_recursive("generate_agg_proof", lambda rc, ctx: rc.aggregation(ctx, a, b))
+        return AggregatableProof("Agg", proof, [pubs])
 
     def empty(self):
         raise NotImplementedError("empty agg proof")          # lib.rs:78-81 unimplemented!
 
 
 class BlockProof:
+    """Operation: Input = GeneratedAggProof, Output = GeneratedBlockProof (lib.rs:84-101)."""
+
     def __init__(self, prev=None):
         self.prev = prev
 
-    def execute(self, input):
-        raise FatalError("generate_block_proof: the block circuit is not available (SURVEY.md 8f-2, A10); zk_prove_plonk proves "
-                         "circuits given as data")
+    def execute(self, input: AggregatableProof) -> GeneratedBlockProof:
+        proof, pubs = _prove_recursive("generate_block_proof", lambda rc, ctx: rc.block(ctx, self.prev, input))
+        height = int(pubs[0]) if len(pubs) else 0
+        return GeneratedBlockProof(height, proof)

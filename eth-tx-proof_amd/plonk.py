@@ -117,3 +117,39 @@ def synthetic_circuit(degree_bits=12, num_wires=135, num_routed=80, n_muladd=16,
                 (OP_SUB, 0, R(0), Lc(e)), (OP_MUL, 0, R(0), Lc(W + 2)), (OP_EMIT, 0, R(0), 0)]
     gates = AirProgram(W + 3, 0, [], [1], ins, 2)
     return Circuit(degree_bits, num_wires, num_routed, consts, sig, gates), np.ascontiguousarray(wires, dtype=np.uint64)
+
+
+class SyntheticRecursion:
+    """STAND-IN for the recursion circuits (ops.RecursionCircuits) so that the reference's caller shape
+    map(&TxProof) -> fold(&AggProof) -> BlockProof (/root/reference/leader/src/prover.rs:26-36) can run end to end on the GPU Plonk
+    prover.  NOT recursion: the circuits are `synthetic_circuit`s of the recursion config's shape and do not verify their children;
+    a child is bound to its parent only through the parent's public inputs, which are the Poseidon digests (hash_no_pad, on the
+    GPU) of the children's proof words.  The real aggregation / block circuits are data a maintainer supplies the same way."""
+
+    def __init__(self, cfg=None, degree_bits=12, seed=1):
+        from ._abi import standard_recursion_config
+        self.cfg = cfg or standard_recursion_config()
+        self.circuits = {"agg": synthetic_circuit(degree_bits=degree_bits, seed=seed),
+                         "block": synthetic_circuit(degree_bits=degree_bits, seed=seed + 1)}
+        self._states = {}
+
+    def state(self, ctx, kind):
+        """The circuit's prover data on this context, built once (upstream: ProverState holds the circuits for the process)."""
+        from . import lib as zl
+        key = (id(ctx), kind)
+        if key not in self._states:
+            self._states[key] = (ctx, zl.PlonkState(ctx, self.cfg, self.circuits[kind][0]))
+        return self._states[key][1]
+
+    @staticmethod
+    def digest(ctx, words):
+        return ctx.hash_rows(np.ascontiguousarray(words, dtype=np.uint64)[None, :])[0]
+
+    def aggregation(self, ctx, lhs, rhs):
+        pubs = np.concatenate([self.digest(ctx, lhs.proof), self.digest(ctx, rhs.proof)])
+        return self.state(ctx, "agg"), self.circuits["agg"][1], pubs
+
+    def block(self, ctx, prev, agg, height=1):
+        prev_d = self.digest(ctx, prev) if prev is not None else np.zeros(4, dtype=np.uint64)
+        pubs = np.concatenate([np.array([height], dtype=np.uint64), self.digest(ctx, agg.proof), prev_d])
+        return self.state(ctx, "block"), self.circuits["block"][1], pubs

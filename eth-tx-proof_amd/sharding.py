@@ -14,20 +14,23 @@ def shard_units(n_units, world, rank):
 
 
 def gather_proofs(local_proofs, n_units, device=None, dst=0):
-    """local_proofs: {unit_index: np.uint64 array (same length for every unit)}.  Returns the list of all proofs in unit
-    order on rank `dst`, None elsewhere."""
+    """local_proofs: {unit_index: np.uint64 array}; lengths may differ between units (different table shapes).  Returns the
+    list of all proofs in unit order on rank `dst`, None elsewhere.  One collective on fixed-size rows: word 0 of a row is the
+    proof's length, the row is padded to the longest proof of the job (one all_reduce MAX finds it)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return [local_proofs[i] for i in range(n_units)]
     per = (n_units + world - 1) // world
-    plen = len(next(iter(local_proofs.values()))) if local_proofs else 0
+    plen = max((len(p) for p in local_proofs.values()), default=0)
     ln = torch.tensor([plen], dtype=torch.int64, device=device)
     dist.all_reduce(ln, op=dist.ReduceOp.MAX)
     plen = int(ln.item())
-    buf = np.zeros((per, plen), dtype=np.uint64)
+    buf = np.zeros((per, 1 + plen), dtype=np.uint64)
     for k, u in enumerate(shard_units(n_units, world, rank)):
-        buf[k] = local_proofs[u]
+        p = local_proofs[u]
+        buf[k, 0] = len(p)
+        buf[k, 1:1 + len(p)] = p
     mine = torch.from_numpy(buf.view(np.int64))
     if device is not None:
         mine = mine.to(device)
@@ -39,5 +42,5 @@ def gather_proofs(local_proofs, n_units, device=None, dst=0):
     for r in range(world):
         arr = out[r].cpu().numpy().view(np.uint64)
         for k, u in enumerate(shard_units(n_units, world, r)):
-            res[u] = arr[k].copy()
+            res[u] = arr[k, 1:1 + int(arr[k, 0])].copy()
     return res

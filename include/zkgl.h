@@ -230,6 +230,10 @@ typedef struct {
     uint32_t num_query_rounds;     /* 84 */
 } zk_stark_config;
 void zk_stark_config_standard_fast(zk_stark_config *out);
+/* the FRI / commitment parameters of plonky2's CircuitConfig::standard_recursion_config() -- rate_bits 3, cap_height 4, PoW 16,
+ * ConstantArityBits(4, 5), 28 query rounds, 2 challenges: what the shrink / root / aggregation / block circuits behind
+ * /root/reference/ops/src/lib.rs:52,72,95 are proved with; for zk_plonk_setup / zk_prove_plonk / zk_fri_prove_instance */
+void zk_stark_config_standard_recursion(zk_stark_config *out);
 
 /* ------------------------------------------------------------------ unit proof
  * One unit of work of the reference's map step (`IndexedStream::from(..).map(&TxProof)`, /root/reference/leader/src/prover.rs:26-27):

@@ -1,9 +1,47 @@
 // Compiles and (on a GPU box) runs the C++ operator mirror: ops::set_prover_state_from_config + ops::TxProof::execute,
-// reading like the reference's call site (/root/reference/ops/src/lib.rs:29-61).  Exit code 0 = proof produced.
+// reading like the reference's call site (/root/reference/ops/src/lib.rs:29-61), then the caller's shape
+// ProverInput::prove = map(&TxProof).fold(&AggProof) -> BlockProof (/root/reference/leader/src/prover.rs:20-43) with a tiny
+// stand-in recursion circuit (identity permutation, no gates: any witness satisfies it).  Exit code 0 = proofs produced.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <vector>
 #include "../../eth-tx-proof_amd/csrc/ops.hpp"
+
+typedef unsigned __int128 u128;
+static const uint64_t GLP = 0xFFFFFFFF00000001ULL;
+static uint64_t fmul(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % GLP); }
+static uint64_t fpow(uint64_t b, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = fmul(r, b); b = fmul(b, b); e >>= 1; } return r; }
+
+// stand-in recursion circuit as plain data: 8 routed wires, 2^4 rows, sigma = identity (sigma_j(w^r) = k_j w^r, k_j = g^j)
+struct TinyCircuit {
+    static constexpr uint32_t K = 4, W = 8, N = 1u << K;
+    zk_stark_config cfg;
+    zk_air gates = {};
+    zk_plonk_circuit circ = {};
+    std::vector<uint64_t> constants, sigmas, wires;
+    zk_plonk_state *state = nullptr;
+    TinyCircuit() {
+        zk_stark_config_standard_recursion(&cfg);
+        gates.n_trace_cols = W + 1; gates.n_regs = 1; gates.constraint_degree = 1;
+        constants.assign(N, 1);
+        const uint64_t w = fpow(7277203076849721926ULL, 1ULL << (32 - K)), g = 14293326489335486720ULL;
+        sigmas.resize((size_t)W * N); wires.resize((size_t)W * N);
+        for (uint32_t j = 0; j < W; j++) {
+            uint64_t x = fpow(g, j);
+            for (uint32_t r = 0; r < N; r++) { sigmas[(size_t)j * N + r] = x; x = fmul(x, w); wires[(size_t)j * N + r] = 1000 * j + r; }
+        }
+        circ.degree_bits = K; circ.num_wires = W; circ.num_routed_wires = W; circ.num_constants = 1; circ.quotient_degree_factor = 8;
+        circ.gates = &gates; circ.constants = constants.data(); circ.sigmas = sigmas.data();
+    }
+    ops::PlonkJob job(zk_ctx *ctx, std::vector<uint64_t> pubs) {
+        if (!state && zk_plonk_setup(ctx, &cfg, &circ, &state) != ZK_OK) throw ops::FatalError(std::string("zk_plonk_setup: ") + zk_last_error(ctx));
+        ops::PlonkJob j;
+        j.cfg = &cfg; j.state = state; j.circuit = &circ; j.wires = wires.data(); j.public_inputs = std::move(pubs);
+        return j;
+    }
+};
 
 int main() {
     // tiny AIR: one column counting up by one (transition constraint next - local - 1 == 0)
@@ -22,7 +60,16 @@ int main() {
     bool threw = false;
     try { ops::p_state(); } catch (const std::logic_error &) { threw = true; }     // "Prover state is not initialized"
     if (!threw) return 2;
-    ops::set_prover_state_from_config(0);
+    static TinyCircuit tiny;
+    ops::RecursionCircuits rec;
+    // children are bound through the public inputs only (first proof word of each child + lengths): a stand-in, not recursion
+    rec.aggregation = [](zk_ctx *ctx, const ops::AggregatableProof &a, const ops::AggregatableProof &b) {
+        return tiny.job(ctx, {a.proof.size(), b.proof.size(), a.proof[1], b.proof[1]});
+    };
+    rec.block = [](zk_ctx *ctx, const std::vector<uint64_t> *prev, const ops::AggregatableProof &agg) {
+        return tiny.job(ctx, {7 /* height */, agg.proof.size(), prev ? prev->size() : 0});
+    };
+    ops::set_prover_state_from_config(0, rec);
     if (ops::set_prover_state_from_config(0)) return 3;                              // second init keeps the first
     ops::GenerationInputs in;
     in.tables.push_back(t);
@@ -30,7 +77,14 @@ int main() {
         ops::AggregatableProof p = ops::TxProof{}.execute(in);
         std::printf("proof words: %zu, magic %016llx\n", p.proof.size(), (unsigned long long)p.proof[0]);
         if (p.proof[0] != 0x31465250474C4B5AULL) return 4;
-        try { ops::AggProof{}.combine(p, p); return 5; } catch (const ops::FatalError &) {}
+        ops::ProverInput job;
+        for (int u = 0; u < 3; u++) job.proof_gen_ir.push_back(in);
+        ops::GeneratedBlockProof blk = job.prove();
+        std::printf("block proof words: %zu, height %llu\n", blk.intern.size(), (unsigned long long)blk.b_height);
+        if (blk.b_height != 7 || blk.intern.size() != zk_plonk_proof_size_words(&tiny.cfg, &tiny.circ)) return 5;
+        ops::ProverInput one;
+        one.proof_gen_ir.push_back(in);
+        try { one.prove(); return 6; } catch (const std::runtime_error &e) { if (!std::strstr(e.what(), "not GeneratedAggProof")) return 7; }
     } catch (const ops::FatalError &e) {
         std::printf("FatalError: %s\n", e.what());
         return 1;                                                                    // expected on a box without a GPU

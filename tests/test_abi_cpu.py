@@ -38,6 +38,14 @@ def test_standard_fast_config(zk):
     assert [getattr(c, f) for f, _ in c._fields_] == [getattr(ref, f) for f, _ in ref._fields_] == [100, 2, 1, 4, 16, 4, 5, 84]
 
 
+def test_standard_recursion_config(zk):
+    from eth_tx_proof_amd._abi import StarkConfig, standard_recursion_config
+    c = StarkConfig()
+    zk.lib().zk_stark_config_standard_recursion(C.byref(c))
+    ref = standard_recursion_config()
+    assert [getattr(c, f) for f, _ in c._fields_] == [getattr(ref, f) for f, _ in ref._fields_] == [100, 2, 3, 4, 16, 4, 5, 28]
+
+
 def _build_ops_smoke(tmp_path):
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

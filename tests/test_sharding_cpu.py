@@ -17,12 +17,14 @@ WORKER = textwrap.dedent("""
     n_units = 5
     mine = sharding.shard_units(n_units, world, rank)
     assert mine == list(range(rank, n_units, world))
-    local = {u: np.full(37, 1000 + u, dtype=np.uint64) + np.arange(37, dtype=np.uint64) for u in mine}   # stand-in proofs
+    # stand-in proofs of DIFFERENT lengths (units with different table shapes)
+    standin = lambda u: np.full(37 + 3 * u, 1000 + u, dtype=np.uint64) + np.arange(37 + 3 * u, dtype=np.uint64)
+    local = {u: standin(u) for u in mine}
     got = sharding.gather_proofs(local, n_units)
     if rank == 0:
         assert len(got) == n_units
         for u in range(n_units):
-            assert (got[u] == np.full(37, 1000 + u, dtype=np.uint64) + np.arange(37, dtype=np.uint64)).all()
+            assert got[u].shape == standin(u).shape and (got[u] == standin(u)).all()
         print("GATHER_OK")
     else:
         assert got is None
@@ -49,3 +51,58 @@ def test_shard_units_cover_everything_once():
         for w in (1, 2, 8):
             allu = sorted(u for r in range(w) for u in sharding.shard_units(n, w, r))
             assert allu == list(range(n))
+
+
+def test_runtime_fold_is_a_balanced_pairwise_tree():
+    sys.path.insert(0, ROOT)
+    import eth_tx_proof_amd  # noqa: F401
+    from eth_tx_proof_amd import leader
+
+    class Cat:
+        def combine(self, a, b):
+            return "(%s%s)" % (a, b)
+
+        def empty(self):
+            raise NotImplementedError("empty agg proof")
+    assert leader.Runtime.fold(Cat(), list("abcde")) == "(((ab)(cd))e)"
+    assert leader.Runtime.fold(Cat(), ["a"]) == "a"
+    import pytest
+    with pytest.raises(NotImplementedError):
+        leader.Runtime.fold(Cat(), [])
+
+
+def test_runtime_map_requeues_device_errors_once():
+    """leader.Runtime.map with a stand-in operator: device errors (ZK_ERR_HIP / ZK_ERR_OOM) are re-queued once, anything else and a
+    second failure abort the job with the FatalError (the GPU version of this test is tests/test_ops_gpu.py)."""
+    sys.path.insert(0, ROOT)
+    import pytest
+    import eth_tx_proof_amd  # noqa: F401
+    from eth_tx_proof_amd import leader, lib as zl, ops
+    old = ops.P_STATE
+    ops.P_STATE = None
+    try:
+        ops.set_prover_state_from_config(0)
+
+        class Op:
+            def __init__(self, fail_unit, times, code):
+                self.fail_unit, self.left, self.code = fail_unit, times, code
+
+            def execute(self, x):
+                if x == self.fail_unit and self.left > 0:
+                    self.left -= 1
+                    try:
+                        raise zl.ZkError(self.code, "zk_prove_tables", "injected")
+                    except zl.ZkError as e:
+                        raise ops.FatalError(str(e)) from e
+                return x * x
+        rt = leader.Runtime(num_workers=3)
+        assert rt.map(Op(4, 1, -3), list(range(9))) == [x * x for x in range(9)]
+        assert [u for u, _ in rt.requeued] == [4]
+        with pytest.raises(ops.FatalError):
+            leader.Runtime(num_workers=3).map(Op(4, 2, -2), list(range(9)))
+        rt = leader.Runtime(num_workers=3)
+        with pytest.raises(ops.FatalError):
+            rt.map(Op(4, 1, -1), list(range(9)))
+        assert rt.requeued == []
+    finally:
+        ops.P_STATE = old
