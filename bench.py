@@ -172,6 +172,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        host_pg = sharding.host_group()       # finished proofs are host buffers: they are handed to rank 0 over gloo
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -218,7 +219,7 @@ def main():
             raise errors[0]
         if world > 1:   # hand finished proofs to rank 0 (the reference's fold(&AggProof) consumes them there)
             mine = {rank + world * s: outs[s] for s in range(args.inflight)}
-            sharding.gather_proofs(mine, args.inflight * world, device=dev)
+            sharding.gather_proofs(mine, args.inflight * world, group=host_pg)
 
     def fence():
         if world > 1:

@@ -82,7 +82,7 @@ class Runtime:
 class ProverInput:
     proof_gen_ir: List[ops.GenerationInputs] = field(default_factory=list)
 
-    def prove(self, runtime: Optional[Runtime] = None, previous: Optional[np.ndarray] = None, device=None):
+    def prove(self, runtime: Optional[Runtime] = None, previous: Optional[np.ndarray] = None, device=None, group=None):
         """-> GeneratedBlockProof on rank 0 (None on the other ranks).  prover.rs:20-43."""
         import torch.distributed as dist
         runtime = runtime or Runtime()
@@ -92,7 +92,7 @@ class ProverInput:
         mine = sharding.shard_units(n, world, rank)
         local = runtime.map(ops.TxProof(), [self.proof_gen_ir[i] for i in mine], indices=mine)      # .map(&TxProof)
         if world > 1:
-            words = sharding.gather_proofs({i: p.proof for i, p in zip(mine, local)}, n, device=device)
+            words = sharding.gather_proofs({i: p.proof for i, p in zip(mine, local)}, n, device=device, group=group)
             if rank != 0:
                 return None
             # public values travel with the inputs (every rank holds proof_gen_ir), the proof words with the gather

@@ -21,6 +21,8 @@ WORKER = textwrap.dedent("""
     standin = lambda u: np.full(37 + 3 * u, 1000 + u, dtype=np.uint64) + np.arange(37 + 3 * u, dtype=np.uint64)
     local = {u: standin(u) for u in mine}
     got = sharding.gather_proofs(local, n_units)
+    again = sharding.gather_proofs(local, n_units, group=sharding.host_group())      # the hand-off group bench.py uses on GPUs
+    assert (got is None) == (again is None) and (got is None or all((a == b).all() for a, b in zip(got, again)))
     if rank == 0:
         assert len(got) == n_units
         for u in range(n_units):
