@@ -258,14 +258,14 @@ __global__ __launch_bounds__(256) void merkle_level_coop_kernel(const u64 *__res
 
 // smallest levels: one parent per WAVE (poseidon_wave.cuh) -- the lowest latency per permutation there is on this chip, for the
 // levels that no longer give every SIMD a wave anyway
-__global__ __launch_bounds__(256) void merkle_level_wave_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parents) {
+__global__ __launch_bounds__(256) void merkle_level_wave_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parents, u64 force_redo) {
     __shared__ u64 wtab[psdw::TAB_WORDS];
     psdw::fill(wtab); __syncthreads();
     const int lane = threadIdx.x & 63;
     const size_t j = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);        // wave-uniform
     if (j >= n_parents) return;
     u64 s = lane < 8 ? child[8 * j + lane] : 0;
-    s = psdw::permute(s, lane, wtab);
+    s = psdw::permute(s, lane, wtab, force_redo);
     if (lane < 4) parent[4 * j + lane] = s;
 }
 
@@ -359,7 +359,7 @@ int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap
             ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_mfma_kernel, dim3((unsigned)(cnt / 2 / 256)), dim3(256), 0, T, (const u64 *)cur, nxt, cnt / 2,
                       ctx->force_redo);
         } else if (cnt / 2 <= 2048 && !(ctx->poseidon_mfma & 8))
-            ZK_LAUNCH(ctx, "poseidon_merkle_level_wave", merkle_level_wave_kernel, dim3((unsigned)((cnt / 2 + 3) / 4)), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
+            ZK_LAUNCH(ctx, "poseidon_merkle_level_wave", merkle_level_wave_kernel, dim3((unsigned)((cnt / 2 + 3) / 4)), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo);
         else if (cnt / 2 <= 16384)
             ZK_LAUNCH(ctx, "poseidon_merkle_level_coop", merkle_level_coop_kernel, grid1(cnt / 2 * 16), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
         else

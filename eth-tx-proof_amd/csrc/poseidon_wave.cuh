@@ -102,10 +102,11 @@ template <bool EXACT> struct perm {
 };
 
 // s: state word `lane` for lane < 12, any representative; all 64 lanes must call.  `tab` = LDS tables (fill()).
-__device__ __forceinline__ u64 permute(u64 s, int lane, const u64 *tab) {
+// force_redo (wave-uniform, ZK_FORCE_EXACT_REDO): always take the exact branch as well -- for the tests.
+__device__ __forceinline__ u64 permute(u64 s, int lane, const u64 *tab, u64 force_redo = 0) {
     perm<false> pf; pf.init(lane, tab);
     u64 r = pf.run(s);
-    if (pf.pc.fl) { perm<true> pe; pe.init(lane, tab); r = pe.run(s); }
+    if (pf.pc.fl | force_redo) { perm<true> pe; pe.init(lane, tab); r = pe.run(s); }
     return r;
 }
 

@@ -12,13 +12,13 @@
 // The kernel runs as ONE wave.  The challenger is staged in LDS; every lane executes the (uniform) control flow, lane 0
 // does the bookkeeping writes, and the permutation is the wave-wide one (poseidon_wave.cuh): state element l in lane l, the
 // whole wave working on the one permutation -- a sponge is a serial chain, so the latency of ONE permutation is all that counts.
-// (ZK_TRANSCRIPT_COOP=1 selects the older 16-lane version, poseidon_coop.cuh, for comparison.)
+// (bit 2 of ZK_POSEIDON_MFMA selects the older 16-lane version, poseidon_coop.cuh, for comparison and for the tests.)
 // One copy of the permutation code in the kernel (every call site jumps here): the instruction stream of a permutation is what
 // the single wave waits for, so it should stay resident in the instruction cache.
 struct ChPerm {
-    const u64 *wtab; bool wave;
+    const u64 *wtab; bool wave; u64 force_redo;
     __device__ __noinline__ u64 run(u64 s, int lane) const {
-        if (wave) return psdw::permute(s, lane, wtab);
+        if (wave) return psdw::permute(s, lane, wtab, force_redo);
         return psdc::permute16(s, lane & 15, lane & ~15);
     }
 };
@@ -48,12 +48,12 @@ __device__ u64 ch_get(DevChallenger *c, ChPerm &P) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpList ops, u64 *err, int wave) {
+__global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpList ops, u64 *err, int wave, u64 force_redo) {
     __shared__ DevChallenger L;
     __shared__ u64 wtab[psdw::TAB_WORDS];
     DevChallenger *c = &L;
     const int lane = threadIdx.x;
-    ChPerm P; P.wave = wave != 0; P.wtab = wtab;
+    ChPerm P; P.wave = wave != 0; P.wtab = wtab; P.force_redo = force_redo;
     if (P.wave) psdw::fill(wtab);
     {
         const u64 *src = (const u64 *)gc; u64 *dst = (u64 *)c;
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void pow_grind_kernel(u64 *pow_state /* 14 wor
 }
 
 int32_t zk_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops) {
-    static const int wave = []() { const char *e = getenv("ZK_TRANSCRIPT_COOP"); return (e && e[0] == '1') ? 0 : 1; }();
-    ZK_LAUNCH(ctx, "transcript", transcript_kernel, dim3(1), dim3(64), 0, c, ops, ctx->d_err, wave);
+    const int wave = (ctx->poseidon_mfma & 4) ? 0 : 1;
+    ZK_LAUNCH(ctx, "transcript", transcript_kernel, dim3(1), dim3(64), 0, c, ops, ctx->d_err, wave, ctx->force_redo);
     return ZK_OK;
 }
 

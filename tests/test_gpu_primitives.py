@@ -172,6 +172,37 @@ def test_challenger(ctx, orc):
     assert (c.compact() == o.compact()).all()
 
 
+@pytest.mark.parametrize("mfma_bits,force", [("3", "0"), ("15", "0"), ("3", "1")])
+def test_challenger_long_sponge_every_permutation_kernel(zk, orc, monkeypatch, mfma_bits, force):
+    """The transcript's permutation: wave-wide (poseidon_wave.cuh, default), 16-lane (bits 2|3 of ZK_POSEIDON_MFMA) and the wave-wide
+    one forced through its exact-redo branch -- thousands of absorbed words (the bulk path of TOP_OBSERVE: what a 2 431-column opening
+    set costs), ragged lengths around the rate, values that need the rare borrow repair, then 100 draws: same as the oracle."""
+    import json, os
+    monkeypatch.setenv("ZK_POSEIDON_MFMA", mfma_bits)
+    monkeypatch.setenv("ZK_FORCE_EXACT_REDO", force)
+    rc = [int(x, 16) for x in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon_rc.json")))["round_constants_hex"]]
+    c2 = zk.Context(0)
+    try:
+        c, o = c2.challenger(), orc.Challenger()
+        rng = np.random.default_rng(77)
+        for n_obs, n_get in ((5000, 3), (7, 1), (8, 0), (9, 2), (1, 1), (0, 2), (2431 * 4 + 3, 100)):
+            xs = field_rand(rng, n_obs)
+            for k in range(0, n_obs, 13):
+                xs[k] = ((1 << 63) - rc[k % 8]) % P         # s-box input 2^63 in the first round when it lands on word k % 8
+            if n_obs:
+                c.observe(xs); o.observe(xs)
+            if n_get:
+                assert (c.get(n_get) == o.get(n_get)).all()
+        assert (c.compact() == o.compact()).all()
+        # Merkle trees whose upper levels run one parent per wave / per 16 lanes
+        rows = field_rand(rng, (4096, 5))
+        cap, dig = c2.merkle_build(rows, 1)
+        ocap, odig = orc.merkle_build(rows, 1)
+        assert (cap == ocap).all() and (dig == odig).all()
+    finally:
+        c2.close()
+
+
 def test_rare_borrow_inputs_take_the_exact_redo(ctx, orc):
     """poseidon.cuh skips the 1-in-2^32 borrow repair of each reduction and redoes the wave exactly when one was needed.
     An S-box input of 2^63 needs it (x^2 = 2^126: high word 2^30 is subtracted from a reduced 0): rows whose j-th element is
