@@ -280,7 +280,7 @@ def main():
 
     # ---- PCIe-inclusive: the same units from host-resident (pinned) traces, never `value`.  Every worker streams its units the way a
     # paladin worker would: while unit k is being proved, unit k+1's trace is already on its way up (zk_trace_upload_async on the
-    # context's copy stream, four DMA parts), so the PCIe transfer hides behind the proof instead of preceding it.
+    # context's copy stream), so the PCIe transfer hides behind the proof instead of preceding it.
     pcie = None
     if not args.no_pcie and world == 1:
         hosts = []
@@ -289,7 +289,7 @@ def main():
             h[...] = ctxs[s].download(traces[s].data_ptr(), (C, n))
             hosts.append(h)
         k = max(2, 2 * args.steps)
-        # what the link gives on this box: one unit's trace, pinned -> device, alone on an idle GPU (the same four-part upload)
+        # what the link gives on this box: one unit's trace, pinned -> device, alone on an idle GPU (the same upload call)
         fence()
         t0 = time.perf_counter()
         d0 = zl.trace_upload_async(ctxs[0], hosts[0])

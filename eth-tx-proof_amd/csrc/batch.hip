@@ -167,12 +167,14 @@ int32_t zk_batch_from_coeffs(zk_ctx *ctx, const uint64_t *cols, uint32_t log_n, 
 }
 int32_t zk_batch_from_values_dev(zk_ctx *ctx, const uint64_t *d_cols, uint32_t log_n, uint32_t n_cols, uint32_t rate_bits,
                                  uint32_t cap_height, zk_batch **out, uint64_t *cap_out) {
+    if (ctx && d_cols) ctx->wait_upload(d_cols);      // a zk_trace_upload_async prefetch into this buffer lands first (device-side wait)
     int32_t rc = zk_batch_commit_dev(ctx, (const u64 *)d_cols, log_n, n_cols, rate_bits, cap_height, 1, out);
     if (rc == ZK_OK && cap_out) rc = zk_batch_get_cap(*out, cap_out);
     return rc;
 }
 int32_t zk_batch_from_coeffs_dev(zk_ctx *ctx, const uint64_t *d_cols, uint32_t log_n, uint32_t n_cols, uint32_t rate_bits,
                                  uint32_t cap_height, zk_batch **out, uint64_t *cap_out) {
+    if (ctx && d_cols) ctx->wait_upload(d_cols);
     int32_t rc = zk_batch_commit_dev(ctx, (const u64 *)d_cols, log_n, n_cols, rate_bits, cap_height, 0, out);
     if (rc == ZK_OK && cap_out) rc = zk_batch_get_cap(*out, cap_out);
     return rc;
