@@ -20,19 +20,41 @@
 typedef int psdm_v4i __attribute__((ext_vector_type(4)));
 typedef int psdm_v16i __attribute__((ext_vector_type(16)));
 
-#define PSDM_LDS_V4 (9 * 64)       // the MDS operand tiles, one 16-byte fragment per (tile, k-step, lane)
+// LDS image per workgroup, in 16-byte fragments: the MDS operand tiles (one per (tile, k-step, lane)), then the accumulator
+// starts Cin_mds | Cin_F | Cin_G2 (four fragments per (.., lane half)) -- 13 KiB
+#define PSDM_LDS_A 576
+#define PSDM_LDS_CMDS (PSDM_LDS_A)
+#define PSDM_LDS_CF (PSDM_LDS_CMDS + 8 * 3 * 2 * 4)
+#define PSDM_LDS_CG2 (PSDM_LDS_CF + 6 * 2 * 4)
+#define PSDM_LDS_V4 (PSDM_LDS_CG2 + 3 * 2 * 4)
 
 namespace psdm {
 
 __device__ __forceinline__ psdm_v4i ld4(const void *p);
 // every workgroup: all threads call this on its `__shared__ psdm_v4i sh[PSDM_LDS_V4]`, then __syncthreads().  The MDS operand is
-// used 8 x 18 times per permutation: reading it from LDS costs no vector registers (36 if held) and no L1 traffic.
+// used 8 x 18 times per permutation: reading it from LDS costs no vector registers (36 if held) and no L1 traffic; the accumulator
+// starts (the same 64 bytes for all 32 lanes of a half: an LDS broadcast) were 132 of the ~200 16-byte global loads per permutation.
 __device__ __forceinline__ void lds_fill(const PsdmTables *T, psdm_v4i *sh) {
-    const psdm_v4i *src = (const psdm_v4i *)&T->A_mds[0][0][0][0];
-    for (u32 i = threadIdx.x; i < PSDM_LDS_V4; i += blockDim.x) sh[i] = src[i];
+    const psdm_v4i *a = (const psdm_v4i *)&T->A_mds[0][0][0][0], *c0 = (const psdm_v4i *)&T->Cin_mds[0][0][0][0],
+                   *c1 = (const psdm_v4i *)&T->Cin_F[0][0][0], *c2 = (const psdm_v4i *)&T->Cin_G2[0][0][0];
+    for (u32 i = threadIdx.x; i < PSDM_LDS_A; i += blockDim.x) sh[i] = a[i];
+    for (u32 i = threadIdx.x; i < PSDM_LDS_CF - PSDM_LDS_CMDS; i += blockDim.x) sh[PSDM_LDS_CMDS + i] = c0[i];
+    for (u32 i = threadIdx.x; i < PSDM_LDS_CG2 - PSDM_LDS_CF; i += blockDim.x) sh[PSDM_LDS_CF + i] = c1[i];
+    for (u32 i = threadIdx.x; i < PSDM_LDS_V4 - PSDM_LDS_CG2; i += blockDim.x) sh[PSDM_LDS_CG2 + i] = c2[i];
+}
+// pointer into the workgroup's LDS image, typed as such: a generic pointer makes hipcc read LDS with flat_load (aperture check,
+// both memory counters) instead of ds_read_b128 with an immediate offset
+typedef __attribute__((address_space(3))) const psdm_v4i *psdm_lds_ptr;
+__device__ __forceinline__ psdm_v16i ld16l(psdm_lds_ptr p) {
+    psdm_v16i v;
+    const psdm_v4i a = p[0], b = p[1], c = p[2], d = p[3];
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    v[8] = c[0]; v[9] = c[1]; v[10] = c[2]; v[11] = c[3]; v[12] = d[0]; v[13] = d[1]; v[14] = d[2]; v[15] = d[3];
+    return v;
 }
 
 __device__ __forceinline__ psdm_v4i ld4(const void *p) { return *(const psdm_v4i *)p; }
+__device__ __forceinline__ psdm_v4i ld4(const __attribute__((address_space(1))) void *p) { return *(const __attribute__((address_space(1))) psdm_v4i *)p; }
 __device__ __forceinline__ psdm_v16i ld16(const int32_t *p) {
     psdm_v16i v;
     psdm_v4i a = ld4(p), b = ld4(p + 4), c = ld4(p + 8), d = ld4(p + 12);
@@ -89,12 +111,12 @@ __device__ __forceinline__ void swap32(u64 &vdst, u64 &src) {
 
 template <bool EXACT> struct perm {
     psd::core<EXACT> pc;
-    const PsdmTables *__restrict__ T;
+    const __attribute__((address_space(1))) PsdmTables *T;     // typed as global memory: global_load with a scalar base, not flat_load
     u32 lane;
     rk K;
-    const psdm_v4i *Alds;      // the workgroup's LDS copy of A_mds (9 KiB), see lds_fill
+    psdm_lds_ptr Alds;         // the workgroup's LDS image (A_mds, then the accumulator starts), see lds_fill
 
-    __device__ __forceinline__ void init(const PsdmTables *tab, u32 lane_, const psdm_v4i *lds) { T = tab; lane = lane_; pc.fl = 0; K.init(); Alds = lds; }
+    __device__ __forceinline__ void init(const PsdmTables *tab, u32 lane_, const psdm_v4i *lds) { T = (const __attribute__((address_space(1))) PsdmTables *)tab; lane = lane_; pc.fl = 0; K.init(); Alds = (psdm_lds_ptr)lds; }
 
     // s <- MDS * s + constants of layer `layer`
     __device__ __forceinline__ void mds(u64 (&s)[2][6], int layer) {
@@ -105,7 +127,7 @@ template <bool EXACT> struct perm {
             for (int k = 0; k < 3; k++) b[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-            const psdm_v16i cin = ld16(&T->Cin_mds[layer][t][lane >> 5][0]);
+            const psdm_v16i cin = ld16l(Alds + PSDM_LDS_CMDS + ((layer * 3 + t) * 2 + (lane >> 5)) * 4);
             const psdm_v4i a0 = Alds[(3 * t + 0) * 64 + lane], a1 = Alds[(3 * t + 1) * 64 + lane], a2 = Alds[(3 * t + 2) * 64 + lane];
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -148,7 +170,7 @@ template <bool EXACT> struct perm {
             // ---- F rows 4b .. 4b+3 for both column tiles, then to one permutation per lane
             u64 F[4];
             {
-                const psdm_v16i cin = ld16(&T->Cin_F[b][lane >> 5][0]);
+                const psdm_v16i cin = ld16l(Alds + PSDM_LDS_CF + (b * 2 + (lane >> 5)) * 4);
                 psdm_v16i acc0 = cin, acc1 = cin;
 #pragma unroll
                 for (int k = 0; k < 3 + b; k++) {
@@ -189,7 +211,7 @@ template <bool EXACT> struct perm {
         // ---- exit map G2 (K = 12 state words + 6 blocks of y), + RC[26]
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-            const psdm_v16i cin = ld16(&T->Cin_G2[t][lane >> 5][0]);
+            const psdm_v16i cin = ld16l(Alds + PSDM_LDS_CG2 + (t * 2 + (lane >> 5)) * 4);
             psdm_v16i acc0 = cin, acc1 = cin;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
@@ -208,7 +230,7 @@ template <bool EXACT> struct perm {
         // accumulator-start loads of every layer out of the caller's loop and keeps ~100 registers alive for them
         asm volatile("" : "+s"(T), "+v"(Alds));
         {
-            const u64 *rc0 = T->RC_first + 6 * (lane >> 5);
+            const auto *rc0 = T->RC_first + 6 * (lane >> 5);
 #pragma unroll
             for (int i = 0; i < 6; i++) { const u64 k = rc0[i]; s[0][i] = psd::wadd_c(s[0][i], k); s[1][i] = psd::wadd_c(s[1][i], k); }
         }

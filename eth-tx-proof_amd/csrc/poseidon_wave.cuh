@@ -36,11 +36,11 @@ __device__ __forceinline__ u64 rdlane64(u64 v, int l) {
 template <bool EXACT> struct perm {
     u32 m[12];              // MDS coefficients of this lane's output row: out_l = sum_i m[i] * s_i
     int lane, lc;
-    const u64 *tab;         // LDS copy of the tables
+    __attribute__((address_space(3))) const u64 *tab;         // LDS copy of the tables, typed as LDS: ds_read, not flat_load
     psd::core<EXACT> pc;
 
     __device__ __forceinline__ void init(int lane_, const u64 *lds_tab) {
-        lane = lane_; lc = lane < 12 ? lane : 0; tab = lds_tab; pc.fl = 0;
+        lane = lane_; lc = lane < 12 ? lane : 0; tab = (__attribute__((address_space(3))) const u64 *)lds_tab; pc.fl = 0;
         // coefficient of s_i in out_l: CIRC[(i - l) mod 12], + 8 on the diagonal of row 0; rows of idle lanes are zero
 #pragma unroll
         for (int i = 0; i < 12; i++) m[i] = (u32)tab[34 * 64 + 64 * i + lane];
@@ -80,7 +80,7 @@ template <bool EXACT> struct perm {
             for (int i = 0; i < 12; i++) a.mac_s(rdlane64(z, i), tab[64 * i + lane]);
             acc = pc.reduce(a);
         }
-        const u64 *ch = tab + 12 * 64 + lane;
+        const auto *ch = tab + 12 * 64 + lane;
         u64 cnext = ch[0];
 #pragma unroll 2
         for (int q = 0; q < 22; q++) {
