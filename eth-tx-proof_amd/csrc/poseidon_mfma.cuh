@@ -200,6 +200,9 @@ template <bool EXACT> struct perm {
                 x = gl_mad_eps(high, ((u64)th << 32) | (u32)al);
 #pragma unroll
                 for (int j = 0; j < i; j++) x = pc.mul_add(Dm[22 * q + 4 * b + j], y[j], x);
+                // the sticky word is brought up to date once per round: left alone, hipcc defers the ORs of the borrow masks across the
+                // unrolled chain and parks ~150 pending masks in VGPR lanes (300 v_writelane / v_readlane per permutation)
+                asm volatile("" : "+s"(pc.fl));
             }
             // ---- the block's s-box outputs to pair layout, as operand bytes
             {
