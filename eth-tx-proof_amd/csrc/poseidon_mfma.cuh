@@ -88,9 +88,12 @@ __device__ __forceinline__ u64 recombine(const rk &K, u32 u0, u32 u1, u32 u2, u3
     const u64 AL = (u64)t1 * K.k16 + t0, AH = (u64)t3 * K.k16 + t2;
     const u64 r = (u64)(u32)(AH >> 32) * K.keps + AL;
     // r + AH.lo 2^32, one wrap repaired by + eps: add into the high word, carry -> mask -> x*1 + acc (the operands are results of
-    // ordinary vector instructions, not of the matrix core, so this may be inline asm)
+    // ordinary vector instructions, not of the matrix core, so this may be inline asm).  s_nop 1: the two wait states between a vector
+    // write of VCC and its vector read (the unpadded pair was exact in every run, but unpadded VCC pairs elsewhere were not --
+    // DESIGN.md section 10 -- and the pad costs nothing measurable in proofs/s)
     u32 rl = (u32)r, rh = (u32)(r >> 32), ahl = (u32)AH, m; u64 w;
     asm("v_add_co_u32 %[rh], vcc, %[rh], %[a]\n\t"
+        "s_nop 1\n\t"
         "v_cndmask_b32_e64 %[m], 0, -1, vcc\n\t"
         : [rh] "+v"(rh), [m] "=&v"(m) : [a] "v"(ahl) : "vcc");
     w = ((u64)rh << 32) | rl;
