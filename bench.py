@@ -380,8 +380,20 @@ def main():
             # NTT GB/s (second half of BASELINE.json's metric): all NTT pass kernels, algorithmic 16 B per element per transform
             ntt_ms = sum(ms for k, (_, ms) in solo.items() if k.startswith("ntt_"))      # NTT kernels of one unit run alone
             L = n << cfg.rate_bits
-            ntt_bytes = 1 * (16 * n * (C + A) + (8 * n + 8 * L) * (C + A + Q) + 16 * L * cfg.num_challenges)
+            # every transform the `ntt_*` launches of one proof perform, each counted once as read + written (8 B per element):
+            #   commits: iNTT of the trace and aux values, LDE (n -> L) of trace, aux and quotient-chunk coefficients, iNTT (size L) of the
+            #   quotient values; FRI (prover_fri.hip): the alpha-combined polynomials onto the LDE coset (2 words x nb opening batches),
+            #   the final values back to coefficients (size L, 2 words), one forward transform per commit-phase layer (2 words)
+            nb = 3 if A else 2
+            fri_layers, d = [], args.log_n
+            while d > cfg.fri_final_poly_bits and d + cfg.rate_bits - cfg.fri_arity_bits >= cfg.cap_height:
+                d -= cfg.fri_arity_bits
+                fri_layers.append(1 << (d + cfg.rate_bits))
+            ntt_bytes_commits = 16 * n * (C + A) + (8 * n + 8 * L) * (C + A + Q) + 16 * L * cfg.num_challenges
+            ntt_bytes_fri = (8 * n + 8 * L) * 2 * nb + 16 * L * 2 + sum(16 * cur * 2 for cur in fri_layers)
+            ntt_bytes = ntt_bytes_commits + ntt_bytes_fri
             line["ntt"] = {"GBps_algorithmic": (ntt_bytes / (ntt_ms * 1e-3) / 1e9) if ntt_ms else None, "ms_per_proof": ntt_ms,
+                           "algorithmic_bytes_per_proof": {"commits": ntt_bytes_commits, "fri": ntt_bytes_fri},
                            "frac_of_hbm_peak": (ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ntt_ms else None}
             line["kernels_one_unit_alone"] = {k: {"launches_per_proof": l, "ms_per_proof_alone": round(ms, 3)}
                                               for k, (l, ms) in sorted(solo.items(), key=lambda kv: -kv[1][1])[:14]}
