@@ -238,7 +238,12 @@ __global__ __launch_bounds__(256) void plonk_quotient_kernel(PlkQuotParams p) {
             regs[(in.dst & 0xFFFFFFu) * 256 + t] = in.op == ZK_OP_ADD ? gl_add(a, b) : in.op == ZK_OP_SUB ? gl_sub(a, b) : gl_mul(a, b);
         } else emit(a);
     }
-    const u64 zi = p.zh_inv[i & (p.qdf - 1)];
+    u64 zi = p.zh_inv[0];                 // select over constant indices: see quotient_block (prover_quotient.hip)
+    {
+        const u32 zsel = i & (p.qdf - 1);
+#pragma unroll
+        for (u32 j = 1; j < 8; j++) zi = zsel == j ? p.zh_inv[j] : zi;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) if ((u32)j < p.nch) p.out[(size_t)j * p.L + s] = gl_mul(acc[j], zi);
 }

@@ -42,7 +42,9 @@ __device__ __forceinline__ u64 q_fetch(const QParams &p, u32 o, const u64 *sh, u
 // instruction stream -- are paid once for two evaluations; both points' accesses stay coalesced.
 // EXACT = false: products through glx<false> (gl64.cuh: the two 1-in-2^32 repairs skipped behind a wave-uniform sticky word); the
 // caller re-runs the slice with EXACT = true when the word comes back non-zero, so the stored values are the same bit for bit.
-template <int NP, bool EXACT> __device__ __forceinline__ u64 quotient_block(const QParams &p, u32 block, u64 *sh) {
+// (`sh`, the temporaries, is typed as LDS: through a generic pointer hipcc reads and writes it with flat instructions)
+typedef __attribute__((address_space(3))) u64 *q_lds_ptr;
+template <int NP, bool EXACT> __device__ __forceinline__ u64 quotient_block(const QParams &p, u32 block, q_lds_ptr sh) {
     glx<EXACT> g; g.fl = 0;
     const u32 n_instrs = (u32)__builtin_amdgcn_readfirstlane((int)p.n_instrs), nch = (u32)__builtin_amdgcn_readfirstlane((int)p.nch);   // wave-uniform, and known to be
     const u32 t = threadIdx.x;
@@ -144,7 +146,12 @@ template <int NP, bool EXACT> __device__ __forceinline__ u64 quotient_block(cons
     }
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-        const u64 zi = p.zh_inv[i[k] & ((1u << p.rate_bits) - 1)];
+        // (a select over constant indices: a run-time index into the by-value parameter struct would pin the WHOLE struct in scratch,
+        // and every pointer in it would then be dereferenced with flat instead of global loads)
+        const u32 zsel = i[k] & ((1u << p.rate_bits) - 1);
+        u64 zi = p.zh_inv[0];
+#pragma unroll
+        for (u32 j = 1; j < 8; j++) zi = zsel == j ? p.zh_inv[j] : zi;
 #pragma unroll
         for (int j = 0; j < 4; j++) if (j < (int)nch) {
             const u64 q = g.mul(acc[k][j], zi);                      // products stay outside lane-dependent control flow
@@ -156,7 +163,7 @@ template <int NP, bool EXACT> __device__ __forceinline__ u64 quotient_block(cons
 __global__ __launch_bounds__(256) void quotient_kernel(QParams p, u64 force_redo) {
     extern __shared__ u64 sh[];
     // temporaries are [reg][point][thread]: a wave only ever touches its own lanes' slots, so a flagged wave can redo its part alone
-    if (quotient_block<2, false>(p, blockIdx.x, sh) | force_redo) quotient_block<2, true>(p, blockIdx.x, sh);
+    if (quotient_block<2, false>(p, blockIdx.x, (q_lds_ptr)sh) | force_redo) quotient_block<2, true>(p, blockIdx.x, (q_lds_ptr)sh);
 }
 __global__ void canon_copy_kernel(const u64 *in, u64 *out, u32 n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
