@@ -49,7 +49,7 @@ def test_prover_input_map_fold_block(orc):
     old = ops.P_STATE
     ops.P_STATE = None
     try:
-        rec = plonk.SyntheticRecursion(degree_bits=8, seed=3)
+        rec = plonk.SyntheticRecursion(degree_bits=7, seed=3)
         st = ops.set_prover_state_from_config(0, recursion=rec)
         prog = air.cpu_like_air(9, 2)
         units, traces = [], []
