@@ -196,6 +196,29 @@ def test_mid_size_bit_exact(ctx, zk, orc):
     assert rc == 0 and (proof == ref).all()
 
 
+@pytest.mark.parametrize("log_n", [18, 20, 21])
+def test_baseline_shape_bit_exact_vs_oracle_up_to_full_size(ctx, zk, orc, log_n):
+    """BASELINE configs[2] itself -- 93 trace + 40 aux columns, standard_fast_config -- at 2^18 rows, at the FULL 2^20 rows and one size
+    up (2^21: the NTT passes change shape): the GPU proof (trace generated in HBM) equals the oracle's proof of the same trace
+    (generated on the host from the same seed) word for word: every cap, opening, FRI layer, the proof-of-work witness and all 84
+    query rounds.  (2^23, north_star's target, is beyond the oracle's prover in a test: verifier-checked below.)"""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(93, 19)
+    seed = 0x5EED0000 + log_n
+    d, pub = zk.synth_trace_dev(ctx, 93, log_n, seed)
+    proof = zk.prove_tables(ctx, cfg, [(prog, log_n, d, pub)])
+    ctx.dev_free(d)
+    tr, opub = orc.synth_trace(93, log_n, seed)
+    assert (opub == pub).all()
+    rc, ref = orc.prove(cfg, [(prog, log_n, tr, opub)])
+    del tr
+    assert rc == 0 and proof.size == ref.size
+    if not (proof == ref).all():
+        bad = np.nonzero(proof != ref)[0]
+        pytest.fail("first differing word %d of %d (%d differ)" % (bad[0], proof.size, bad.size))
+
+
 def test_2_17_rows_narrow_table_bit_exact_both_permutation_paths(zk, orc, monkeypatch):
     """2^17 rows x 9 columns: the first FRI layer has 2^14 leaves, so the matrix-core FRI-leaf kernel, leaf kernel and Merkle-level kernel
     all take part (and, with ZK_POSEIDON_MFMA=0, none of them); both proofs must equal the oracle's word for word."""
@@ -328,16 +351,14 @@ def test_lookup_argument_columns_and_proof_bit_exact(ctx, zk, orc, n_looked, fil
     assert orc.verify(cfg, [(prog, log_n, None, pub)], zk.prove_tables(ctx, cfg, [(prog, log_n, bad, pub)])) != 0
 
 
-def test_cfg4_small_tables_at_their_real_sizes_bit_exact(ctx, zk, orc):
-    """BASELINE configs[3]: BytePacking (71 x 2^9), Cpu (93 x 2^12), KeccakSponge (430 x 2^9) and Logic (523 x 2^12) at their real
-    sizes and widths, Arithmetic / Keccak / Memory at reduced heights (the oracle's prover would take minutes at 2^15 / 2^14 x 2431 /
-    2^17), all seven on one challenger in table order: the GPU proof equals the oracle's word for word.  (The full shape is
-    verifier-checked in test_cfg4_seven_table_shapes.)"""
+def test_cfg4_all_seven_tables_at_their_real_sizes_bit_exact(ctx, zk, orc):
+    """BASELINE configs[3] in full: Arithmetic (165 x 2^15), BytePacking (71 x 2^9), Cpu (93 x 2^12), Keccak (2431 x 2^14),
+    KeccakSponge (430 x 2^9), Logic (523 x 2^12), Memory (21 x 2^17) -- recalled zkEVM widths, all seven on one challenger in table
+    order: the GPU proof equals the oracle's word for word, and the oracle's verifier accepts it."""
     from eth_tx_proof_amd import air
     cfg = _cfg()
-    shapes = list(zip(air.ZKEVM_TABLE_WIDTHS, (11, 9, 12, 8, 9, 12, 12)))        # real: 15, 9, 12, 14, 9, 12, 17
     items = []
-    for t, (w, lg) in enumerate(shapes):
+    for t, (w, lg) in enumerate(zip(air.ZKEVM_TABLE_WIDTHS, air.ZKEVM_CFG4_LOG_SIZES)):
         prog = air.cpu_like_air(w, min(19, w // 4))
         tr, pub = orc.synth_trace(w, lg, 0x5EED0000 + 1000 * t)
         items.append((prog, lg, tr, pub))

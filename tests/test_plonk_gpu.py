@@ -12,7 +12,7 @@ def _cfg():
     return E.standard_recursion_config()
 
 
-@pytest.mark.parametrize("degree_bits,seed", [(6, 1), (9, 2), (12, 3), (13, 4)])
+@pytest.mark.parametrize("degree_bits,seed", [(6, 1), (9, 2), (12, 3), (13, 4), (14, 5)])
 def test_plonk_proof_bit_exact_vs_oracle(ctx, zk, orc, degree_bits, seed):
     from eth_tx_proof_amd import plonk
     cfg = _cfg()
