@@ -30,6 +30,28 @@ def test_proof_bit_exact_vs_oracle(ctx, zk, orc, n_cols, n_helpers, log_n):
     assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
 
 
+SWEEP = [(1, 0, 3), (2, 0, 3), (3, 1, 4), (8, 2, 5), (16, 4, 6), (17, 4, 7), (40, 10, 9), (135, 19, 7), (200, 19, 8), (33, 8, 11), (64, 16, 12),
+         (4, 1, 15), (9, 2, 16), (5, 0, 17), (165, 19, 10), (71, 17, 9), (21, 5, 14), (430, 19, 6), (523, 19, 5), (2431, 19, 4)]
+
+
+@pytest.mark.parametrize("n_cols,n_helpers,log_n", SWEEP)
+def test_proof_shape_sweep_bit_exact(ctx, zk, orc, n_cols, n_helpers, log_n):
+    """Shapes around every edge the prover has: the smallest tree (2^3 rows: the LDE is exactly the cap), one column, widths that are
+    not a multiple of the sponge rate, no auxiliary columns, the zkEVM table widths (up to 2 431 columns), tall narrow tables whose
+    Merkle and FRI layers cross every kernel-selection threshold.  Whole proof equal to the oracle's, and the verifier accepts it."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    prog = air.cpu_like_air(n_cols, n_helpers)
+    tr, pub = orc.synth_trace(n_cols, log_n, 0xABC0000 + 31 * n_cols + log_n)
+    proof = zk.prove_tables(ctx, cfg, [(prog, log_n, tr, pub)])
+    rc, ref = orc.prove(cfg, [(prog, log_n, tr, pub)])
+    assert rc == 0 and proof.size == ref.size
+    if not (proof == ref).all():
+        bad = np.nonzero(proof != ref)[0]
+        pytest.fail("first differing word %d of %d (%d differ)" % (bad[0], proof.size, bad.size))
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
+
+
 def test_multi_table_bit_exact(ctx, zk, orc):
     """cfg4 shape at reduced sizes: several tables, one challenger, tables proved in order"""
     from eth_tx_proof_amd import air
