@@ -366,7 +366,8 @@ int32_t zk_fri_commit_free(zk_fri_commit *s);
 typedef struct {
     uint32_t degree_bits;             /* n = 2^degree_bits rows */
     uint32_t num_wires;               /* 135 */
-    uint32_t num_routed_wires;        /* 80 */
+    uint32_t num_routed_wires;        /* 80; a multiple of quotient_degree_factor, at most 16 chunks of it (128 at factor 8):
+                                       * wider permutations are refused with ZK_ERR_INVALID_ARG (upstream has no such limit) */
     uint32_t num_constants;           /* constant + selector columns */
     uint32_t quotient_degree_factor;  /* 8: chunk size of the partial products, number of quotient chunks per challenge */
     uint32_t reserved;

@@ -75,3 +75,38 @@ def test_plonk_error_paths(ctx, zk):
         zk.prove_plonk(st, wires, np.zeros(1, dtype=np.uint64))
     st.cfg = cfg
     st.free()
+
+
+@pytest.mark.parametrize("k,num_wires,num_routed,n_muladd,n_sbox", [(2, 16, 8, 2, 1), (3, 16, 8, 2, 1), (4, 24, 16, 4, 2), (5, 40, 16, 4, 2), (8, 64, 24, 8, 8),
+                                                                     (7, 135, 80, 16, 8), (10, 135, 80, 30, 20), (6, 170, 128, 20, 10), (9, 9, 8, 1, 0)])
+def test_plonk_circuit_shape_sweep_bit_exact(ctx, zk, orc, k, num_wires, num_routed, n_muladd, n_sbox):
+    """Circuit shapes away from the recursion config's: the smallest domains (2^2, 2^3 rows: the 8n coset is the cap), one partial-product
+    chunk (8 routed wires) up to the sixteen the kernels hold (128), more wires than the recursion config, a circuit with a single gate kind.  Same proof
+    words as the oracle, verifier accepts."""
+    from eth_tx_proof_amd import plonk
+    cfg = _cfg()
+    circ, wires = plonk.synthetic_circuit(degree_bits=k, num_wires=num_wires, num_routed=num_routed, n_muladd=n_muladd, n_sbox=n_sbox, seed=100 + k)
+    pub = np.array([k, num_wires, num_routed], dtype=np.uint64)
+    ost = orc.PlonkState(cfg, circ)
+    st = zk.PlonkState(ctx, cfg, circ)
+    try:
+        assert (st.digest() == ost.digest()).all()
+        proof = zk.prove_plonk(st, wires, pub)
+        rc, ref = orc.prove_plonk(ost, wires, pub)
+        assert rc == 0 and proof.size == ref.size
+        if not (proof == ref).all():
+            bad = np.nonzero(proof != ref)[0]
+            pytest.fail("first differing word %d of %d (%d differ)" % (bad[0], proof.size, bad.size))
+        assert orc.verify_plonk(ost, pub, proof) == 0
+    finally:
+        st.free()
+
+
+def test_plonk_more_than_sixteen_chunks_is_refused(ctx, zk):
+    """include/zkgl.h: at most 16 chunks of routed wires (128 at quotient degree factor 8) -- a documented limit of this prover, not
+    of upstream: refused with ZK_ERR_INVALID_ARG, loudly, before any work."""
+    from eth_tx_proof_amd import plonk
+    circ, _ = plonk.synthetic_circuit(degree_bits=4, num_wires=160, num_routed=136, n_muladd=2, n_sbox=1, seed=1)
+    with pytest.raises(zk.ZkError) as e:
+        zk.PlonkState(ctx, _cfg(), circ)
+    assert e.value.code == -1
