@@ -43,11 +43,24 @@ struct FriBatchDesc { u64 point[2]; u32 n_polys; const zk_fri_poly *polys; };
 int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *const *oracles, u32 n_oracles,
                                   const FriBatchDesc *batches, u32 n_batches, u64 *d_proof, const FriLayout &lay);
 
-static inline void zk_fri_arities(const zk_stark_config &cfg, u32 degree_bits, u32 *out, u32 *n_out) {
+// FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (plonky2 0.2.2 fri/reduction_strategies.rs):
+//   while degree_bits > final_poly_bits && degree_bits + rate_bits - arity_bits >= cap_height { push; assert!(degree_bits >= arity_bits); .. }
+// upstream computes in usize: when degree_bits + rate_bits < arity_bits the subtraction underflows and, like a failing assert, PANICS.
+// Returns false for exactly those (config, size) pairs -- the entry points turn that into ZK_ERR_INVALID_ARG -- and never loops.
+static inline bool zk_fri_arities_checked(const zk_stark_config &cfg, u32 degree_bits, u32 *out, u32 *n_out) {
     u32 d = degree_bits, k = 0;
-    while (d > cfg.fri_final_poly_bits && d + cfg.rate_bits - cfg.fri_arity_bits >= cfg.cap_height) { out[k++] = cfg.fri_arity_bits; d -= cfg.fri_arity_bits; }
+    bool ok = cfg.fri_arity_bits != 0;
+    while (ok && d > cfg.fri_final_poly_bits) {
+        if (d + cfg.rate_bits < cfg.fri_arity_bits) { ok = false; break; }
+        if (d + cfg.rate_bits - cfg.fri_arity_bits < cfg.cap_height) break;
+        if (d < cfg.fri_arity_bits || k >= 64) { ok = false; break; }
+        out[k++] = cfg.fri_arity_bits; d -= cfg.fri_arity_bits;
+    }
     *n_out = k;
+    return ok;
 }
+static inline void zk_fri_arities(const zk_stark_config &cfg, u32 degree_bits, u32 *out, u32 *n_out) { (void)zk_fri_arities_checked(cfg, degree_bits, out, n_out); }
+static inline bool zk_fri_reduction_ok(const zk_stark_config &cfg, u32 degree_bits) { u32 ar[64], nl; return zk_fri_arities_checked(cfg, degree_bits, ar, &nl); }
 
 // prover_quotient.hip: L_first | L_last (two columns of L = n << rate_bits) on the coset g*H_L, leaf order; cached per (log_n, rate_bits)
 int32_t zk_lagrange_table(zk_ctx *ctx, u32 log_n, u32 rate_bits, u64 **out);

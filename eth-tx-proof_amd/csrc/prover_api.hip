@@ -140,7 +140,7 @@ int32_t zk_pow_grind(zk_ctx *ctx, const uint64_t state[12], uint32_t pos, uint32
 }
 
 size_t zk_fri_proof_size_words(const zk_stark_config *cfg, uint32_t log_n, uint32_t n_trace_cols, uint32_t n_aux_cols) {
-    if (!cfg) return 0;
+    if (!cfg || log_n + cfg->rate_bits < cfg->cap_height || !zk_fri_reduction_ok(*cfg, log_n)) return 0;
     const u32 capw = 4u << cfg->cap_height, Q = cfg->num_challenges << cfg->rate_bits, lgL = log_n + cfg->rate_bits;
     u32 ar[64], nl; zk_fri_arities(*cfg, log_n, ar, &nl);
     u32 d = log_n; for (u32 l = 0; l < nl; l++) d -= ar[l];
@@ -203,7 +203,7 @@ int32_t zk_fri_prove_openings(zk_ctx *ctx, const zk_stark_config *cfg, zk_batch 
 }
 
 size_t zk_fri_instance_proof_size_words(const zk_stark_config *cfg, uint32_t log_n, uint32_t n_oracles, const uint32_t *oracle_n_cols) {
-    if (!cfg || !oracle_n_cols || cfg->num_query_rounds == 0) return 0;
+    if (!cfg || !oracle_n_cols || cfg->num_query_rounds == 0 || log_n + cfg->rate_bits < cfg->cap_height || !zk_fri_reduction_ok(*cfg, log_n)) return 0;
     const u32 capw = 4u << cfg->cap_height, lgL = log_n + cfg->rate_bits;
     u32 ar[64], nl; zk_fri_arities(*cfg, log_n, ar, &nl);
     u32 d = log_n; for (u32 l = 0; l < nl; l++) d -= ar[l];
@@ -229,6 +229,7 @@ int32_t zk_fri_prove_instance(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t 
     hipSetDevice(ctx->device);
     const u32 log_n = oracles[0]->log_n;
     if (log_n + cfg->rate_bits < cfg->cap_height) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: cap_height above the tree");
+    if (!zk_fri_reduction_ok(*cfg, log_n)) return ctx->fail(ZK_ERR_INVALID_ARG, "fri instance: the reduction strategy does not fit this size (upstream panics)");
     const size_t fri_words = zk_fri_instance_proof_size_words(cfg, log_n, n_oracles, ncols);
     if (len_words) *len_words = fri_words;
     if (cap_words < fri_words) return ZK_ERR_BUFFER_TOO_SMALL;

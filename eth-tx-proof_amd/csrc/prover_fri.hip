@@ -591,6 +591,7 @@ int32_t zk_fri_commit_begin(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t lo
     *out = nullptr;
     if (cfg->rate_bits > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits < 2 || cfg->fri_arity_bits > 6 || log_n > 26 || log_n + cfg->rate_bits < cfg->cap_height)
         return ctx->fail(ZK_ERR_INVALID_ARG, "fri commit: unsupported FRI parameters");
+    if (!zk_fri_reduction_ok(*cfg, log_n)) return ctx->fail(ZK_ERR_INVALID_ARG, "fri commit: the reduction strategy does not fit this size (upstream panics)");
     hipSetDevice(ctx->device);
     zk_fri_commit *s = new zk_fri_commit();
     s->ctx = ctx; s->cfg = *cfg; s->log_n = log_n; s->lgL = log_n + cfg->rate_bits; s->done = 0; s->finished = false;

@@ -82,6 +82,8 @@ static TableLayout table_layout(const zk_stark_config &cfg, const zk_table &t, s
 
 extern "C" size_t zk_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables) {
     if (!cfg || !tables) return 0;
+    for (u32 t = 0; t < n_tables; t++)
+        if (!tables[t].air || tables[t].log_n + cfg->rate_bits < cfg->cap_height || !zk_fri_reduction_ok(*cfg, tables[t].log_n)) return 0;
     size_t o = 2;
     for (u32 t = 0; t < n_tables; t++) o = table_layout(*cfg, tables[t], o).end;
     return o;
@@ -118,6 +120,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
     for (u32 t = 0; t < nt; t++) {
         if (!tables[t].air || !tables[t].trace || tables[t].log_n > 26 || tables[t].log_n + cfg.rate_bits < cfg.cap_height)
             return ctx->fail(ZK_ERR_INVALID_ARG, "prove: bad table");
+        if (!zk_fri_reduction_ok(cfg, tables[t].log_n)) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: the FRI reduction strategy does not fit this table size (upstream panics)");
         if (zk_air_validate(tables[t].air, cfg.num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: malformed AIR (zk_air_validate)");
         if (tables[t].air->n_public_inputs && !tables[t].public_inputs) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: public inputs missing");
     }

@@ -44,7 +44,7 @@ static int32_t plonk_circuit_check(const zk_stark_config *cfg, const zk_plonk_ci
         c->num_routed_wires / c->quotient_degree_factor > PLK_MAX_CHUNKS)
         return ZK_ERR_INVALID_ARG;
     if (cfg->num_challenges == 0 || cfg->num_challenges > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits < 2 || cfg->fri_arity_bits > 6 || cfg->num_query_rounds == 0 ||
-        cfg->proof_of_work_bits > 34 || c->degree_bits + cfg->rate_bits < cfg->cap_height)
+        cfg->proof_of_work_bits > 34 || c->degree_bits + cfg->rate_bits < cfg->cap_height || !zk_fri_reduction_ok(*cfg, c->degree_bits))
         return ZK_ERR_INVALID_ARG;
     const zk_air *g = c->gates;
     if ((g->n_instrs && !g->instrs) || (g->n_constants && !g->constants) || g->n_regs == 0 || g->n_regs > 24 || g->n_instrs > (1u << 20)) return ZK_ERR_INVALID_ARG;

@@ -20,11 +20,21 @@ static void pn(pw *w, const uint64_t *v, size_t n) { for (size_t i = 0; i < n; i
 
 static uint32_t brev(uint32_t x, uint32_t bits) { uint32_t r = 0; for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 
-static void fri_arities_p(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) {
+/* FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (A8).  Upstream computes in usize and asserts degree_bits >=
+ * arity_bits: a (config, size) pair whose subtraction would underflow or whose assert would fail PANICS there; returns 0 for those. */
+static int fri_arities_p_checked(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) {
     uint32_t d = degree_bits, k = 0;
-    while (d > cfg->fri_final_poly_bits && d + cfg->rate_bits - cfg->fri_arity_bits >= cfg->cap_height) { out[k++] = cfg->fri_arity_bits; d -= cfg->fri_arity_bits; }
+    int ok = cfg->fri_arity_bits != 0;
+    while (ok && d > cfg->fri_final_poly_bits) {
+        if (d + cfg->rate_bits < cfg->fri_arity_bits) { ok = 0; break; }
+        if (d + cfg->rate_bits - cfg->fri_arity_bits < cfg->cap_height) break;
+        if (d < cfg->fri_arity_bits || k >= 64) { ok = 0; break; }
+        out[k++] = cfg->fri_arity_bits; d -= cfg->fri_arity_bits;
+    }
     *n_out = k;
+    return ok;
 }
+static void fri_arities_p(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) { (void)fri_arities_p_checked(cfg, degree_bits, out, n_out); }
 
 /* gate program over the base field: LOCAL i < W is wire i, otherwise constant column i - W.  Emitted terms are appended to out. */
 static uint32_t gates_base(const zk_air *g, const uint64_t *wires, const uint64_t *consts, uint32_t W, uint64_t *regs, uint64_t *out) {
@@ -64,6 +74,7 @@ static int circuit_ok(const zk_stark_config *cfg, const zk_plonk_circuit *c) {
     if (c->degree_bits < 2 || c->degree_bits > 24 || c->num_wires == 0 || c->num_routed_wires == 0 || c->num_routed_wires > c->num_wires) return 0;
     if (c->quotient_degree_factor != (1u << cfg->rate_bits) || c->num_routed_wires % c->quotient_degree_factor) return 0;
     if (cfg->num_challenges == 0 || cfg->num_challenges > 4) return 0;
+    { uint32_t ar_[64], nl_; if (c->degree_bits + cfg->rate_bits < cfg->cap_height || !fri_arities_p_checked(cfg, c->degree_bits, ar_, &nl_)) return 0; }
     for (uint32_t p = 0; p < c->gates->n_instrs; p++) {
         const zk_instr *in = &c->gates->instrs[p];
         if (in->op > ZK_OP_EMIT) return 0;

@@ -165,12 +165,21 @@ typedef struct { uint64_t *p; size_t cap, len; int overflow; } wr;
 static void w1(wr *w, uint64_t v) { if (w->len < w->cap) w->p[w->len] = v; else w->overflow = 1; w->len++; }
 static void wn(wr *w, const uint64_t *v, size_t n) { for (size_t i = 0; i < n; i++) w1(w, v[i]); }
 
-static void fri_arities(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) {
-    /* FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (A8) */
+/* FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (A8).  Upstream computes in usize and asserts degree_bits >=
+ * arity_bits: a (config, size) pair whose subtraction would underflow or whose assert would fail PANICS there; returns 0 for those. */
+static int fri_arities_checked(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) {
     uint32_t d = degree_bits, k = 0;
-    while (d > cfg->fri_final_poly_bits && d + cfg->rate_bits - cfg->fri_arity_bits >= cfg->cap_height) { out[k++] = cfg->fri_arity_bits; d -= cfg->fri_arity_bits; }
+    int ok = cfg->fri_arity_bits != 0;
+    while (ok && d > cfg->fri_final_poly_bits) {
+        if (d + cfg->rate_bits < cfg->fri_arity_bits) { ok = 0; break; }
+        if (d + cfg->rate_bits - cfg->fri_arity_bits < cfg->cap_height) break;
+        if (d < cfg->fri_arity_bits || k >= 64) { ok = 0; break; }
+        out[k++] = cfg->fri_arity_bits; d -= cfg->fri_arity_bits;
+    }
     *n_out = k;
+    return ok;
 }
+static void fri_arities(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) { (void)fri_arities_checked(cfg, degree_bits, out, n_out); }
 
 static void ext_fft_coset(gl2 *v, uint32_t lg, uint64_t shift) {
     /* coset_fft over the extension: the shift and the roots are base-field, so it acts component-wise */
@@ -410,7 +419,12 @@ static uint64_t *quotient_polys(const zk_stark_config *cfg, tbl_state *T, const 
 }
 
 int32_t orc_prove(const zk_stark_config *cfg, uint32_t nt, const orc_table *tables, uint64_t *out, size_t cap_words, size_t *len_words) {
-    if (cfg->num_challenges > 8 || cfg->rate_bits > 3 || cfg->cap_height > 6) return ZK_ERR_INVALID_ARG;
+    /* the same parameter window as the product (include/zkgl.h, zk_prove_tables), so that refusals can be compared too */
+    if (cfg->num_challenges == 0 || cfg->num_challenges > 4 || cfg->rate_bits > 3 || cfg->cap_height > 8 || cfg->fri_arity_bits < 2 || cfg->fri_arity_bits > 6) return ZK_ERR_INVALID_ARG;
+    for (uint32_t t = 0; t < nt; t++) {
+        uint32_t ar_[64], nl_;
+        if (tables[t].log_n > 26 || tables[t].log_n + cfg->rate_bits < cfg->cap_height || !fri_arities_checked(cfg, tables[t].log_n, ar_, &nl_)) return ZK_ERR_INVALID_ARG;
+    }
     if ((cfg->rate_bits != 1)) return ZK_ERR_INVALID_ARG; /* quotient_degree_bits == rate_bits == 1 only (constraint degree 3) */
     wr w = {out, cap_words, 0, 0};
     uint32_t nch = cfg->num_challenges, capw = 4u << cfg->cap_height;
@@ -490,6 +504,10 @@ int32_t orc_prove(const zk_stark_config *cfg, uint32_t nt, const orc_table *tabl
 
 size_t orc_proof_size_words(const zk_stark_config *cfg, uint32_t nt, const orc_table *tables) {
     size_t tot = 2;
+    for (uint32_t t = 0; t < nt; t++) {   /* no such tree / upstream panics in the reduction strategy: orc_prove refuses */
+        uint32_t ar_[64], nl_;
+        if (tables[t].log_n + cfg->rate_bits < cfg->cap_height || !fri_arities_checked(cfg, tables[t].log_n, ar_, &nl_)) return 0;
+    }
     uint32_t nch = cfg->num_challenges, capw = 4u << cfg->cap_height;
     for (uint32_t t = 0; t < nt; t++) {
         uint32_t C = tables[t].air->n_trace_cols, A = n_aux_cols(tables[t].air, nch), Q = nch << cfg->rate_bits;
@@ -574,6 +592,7 @@ int32_t orc_fri_prove_instance(const zk_stark_config *cfg, uint32_t n_oracles, c
             if (pl[b][k].oracle_index >= n_oracles || pl[b][k].polynomial_index >= oracles[pl[b][k].oracle_index]->n_cols) return ZK_ERR_INVALID_ARG;
     }
     for (uint32_t o = 1; o < n_oracles; o++) if (oracles[o]->log_n != oracles[0]->log_n) return ZK_ERR_INVALID_ARG;
+    { uint32_t ar_[64], nl_; if (oracles[0]->log_n + cfg->rate_bits < cfg->cap_height || !fri_arities_checked(cfg, oracles[0]->log_n, ar_, &nl_)) return ZK_ERR_INVALID_ARG; }
     fri_instance I = {n_oracles, oracles, n_batches, points, cnt, pl};
     wr w = {out, cap_words, 0, 0};
     int32_t rc = fri_prove_instance(cfg, &I, ch, &w);

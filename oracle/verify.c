@@ -51,11 +51,21 @@ static void eval_ext(const zk_air *air, const xctx *e, uint32_t nch, const uint6
     free(regs);
 }
 
-static void fri_arities(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) {
+/* FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (A8).  Upstream computes in usize and asserts degree_bits >=
+ * arity_bits: a (config, size) pair whose subtraction would underflow or whose assert would fail PANICS there; returns 0 for those. */
+static int fri_arities_checked(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) {
     uint32_t d = degree_bits, k = 0;
-    while (d > cfg->fri_final_poly_bits && d + cfg->rate_bits - cfg->fri_arity_bits >= cfg->cap_height) { out[k++] = cfg->fri_arity_bits; d -= cfg->fri_arity_bits; }
+    int ok = cfg->fri_arity_bits != 0;
+    while (ok && d > cfg->fri_final_poly_bits) {
+        if (d + cfg->rate_bits < cfg->fri_arity_bits) { ok = 0; break; }
+        if (d + cfg->rate_bits - cfg->fri_arity_bits < cfg->cap_height) break;
+        if (d < cfg->fri_arity_bits || k >= 64) { ok = 0; break; }
+        out[k++] = cfg->fri_arity_bits; d -= cfg->fri_arity_bits;
+    }
     *n_out = k;
+    return ok;
 }
+static void fri_arities(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) { (void)fri_arities_checked(cfg, degree_bits, out, n_out); }
 
 #define FAIL(code) do { rc = (code); goto done; } while (0)
 
@@ -141,7 +151,8 @@ int32_t orc_verify(const zk_stark_config *cfg, uint32_t nt, const orc_table *tab
         /* ---- FRI */
         uint64_t ab[2]; orc_challenger_get_n(&ch, 2, ab);
         gl2 alpha = {ab[0], ab[1]};
-        uint32_t ar[64], nl; fri_arities(cfg, log_n, ar, &nl);
+        uint32_t ar[64], nl;
+        if (!fri_arities_checked(cfg, log_n, ar, &nl)) FAIL(129);      /* a (config, size) pair upstream panics on: no valid proof exists */
         if (r1(&r) != nl) FAIL(130);
         const uint64_t *layer_caps[64]; gl2 betas[64];
         for (uint32_t l = 0; l < nl; l++) {

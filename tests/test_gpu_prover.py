@@ -52,6 +52,33 @@ def test_proof_shape_sweep_bit_exact(ctx, zk, orc, n_cols, n_helpers, log_n):
     assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
 
 
+CFG_SWEEP = [(100, 1, 1, 0, 0, 2, 2, 5), (100, 3, 1, 2, 10, 3, 4, 20), (100, 2, 1, 6, 8, 5, 3, 40), (100, 4, 1, 4, 12, 4, 5, 10), (100, 2, 1, 8, 4, 6, 1, 7),
+             (100, 2, 1, 3, 20, 4, 0, 3), (100, 2, 1, 4, 16, 4, 5, 84), (100, 2, 1, 5, 1, 2, 6, 9)]
+
+
+@pytest.mark.parametrize("c", CFG_SWEEP)
+def test_stark_config_sweep_bit_exact_or_refused_alike(ctx, zk, orc, c):
+    """StarkConfig away from standard_fast_config: 1 to 4 challenges, cap heights 0 to 8, no proof of work up to 20 bits, FRI arities
+    4 to 64, final polynomials of 1 to 64 coefficients, 3 to 84 query rounds.  Whatever the oracle does with a (config, table) pair
+    the GPU does too: the same proof words, or both refuse.  (The synthetic AIR's auxiliary columns are laid out for two challenges,
+    so tables with helper columns appear under two challenges only.)"""
+    from eth_tx_proof_amd import air
+    from eth_tx_proof_amd._abi import StarkConfig
+    cfg = StarkConfig(*c)
+    shapes = [(12, 0, 11), (5, 0, 6)] + ([(7, 2, 8), (21, 4, 10)] if cfg.num_challenges == 2 else [])
+    for n_cols, n_helpers, log_n in shapes:
+        prog = air.cpu_like_air(n_cols, n_helpers)
+        tr, pub = orc.synth_trace(n_cols, log_n, 0xC0F + log_n)
+        rc, ref = orc.prove(cfg, [(prog, log_n, tr, pub)])
+        if rc != 0:
+            with pytest.raises(zk.ZkError):
+                zk.prove_tables(ctx, cfg, [(prog, log_n, tr, pub)])
+            continue
+        proof = zk.prove_tables(ctx, cfg, [(prog, log_n, tr, pub)])
+        assert proof.size == ref.size and (proof == ref).all(), (c, n_cols, n_helpers, log_n)
+        assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
+
+
 def test_multi_table_bit_exact(ctx, zk, orc):
     """cfg4 shape at reduced sizes: several tables, one challenger, tables proved in order"""
     from eth_tx_proof_amd import air
