@@ -260,7 +260,9 @@ typedef struct {
 } zk_table;
 size_t zk_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables);
 /* Parameter window (ZK_ERR_INVALID_ARG outside it; upstream's own limits are wider): 1..4 challenges, rate_bits 1 (constraint degree 3:
- * quotient_degree_factor 2), cap_height <= 8 and <= log_n + rate_bits, FRI arity bits 2..6, log_n <= 26. */
+ * quotient_degree_factor 2), cap_height <= 8 and <= log_n + rate_bits, FRI arity bits 2..6, log_n <= 26.  A (config, log_n) pair on
+ * which upstream's FriReductionStrategy::ConstantArityBits panics (usize underflow of degree_bits + rate_bits - arity_bits, or its
+ * assert!(degree_bits >= arity_bits)) is refused the same way; zk_proof_size_words returns 0 for every refused combination. */
 int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables,
                         uint64_t *proof_out, size_t proof_cap_words, size_t *proof_len_words);
 /* Prover state: what the reference builds once at start-up (common/src/prover_state/mod.rs:59-95, used through
