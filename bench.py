@@ -169,9 +169,17 @@ def main():
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU over RCCL.  ZK_BENCH_BACKEND=gloo is a REHEARSAL switch: it lets several ranks share one card (RCCL refuses
+    # that), so that the N > 1 code path -- sharded units, pipelined steps, the proof hand-off -- runs for real on a one-GPU box
+    backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         host_pg = sharding.host_group()       # finished proofs are host buffers: they are handed to rank 0 over gloo
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -241,7 +249,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else None)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt

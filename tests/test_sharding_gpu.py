@@ -73,3 +73,19 @@ def test_sixteen_unit_block_sharded_proved_gathered_verified(tmp_path):
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, (out.stdout[-1500:] + out.stderr[-3000:])
     assert "BLOCK_OK" in out.stdout
+
+
+def test_bench_two_rank_path_rehearsed_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path -- units sharded over ranks, pipelined steps, finished proofs handed to rank 0 over the host group, max-over-
+    ranks timing -- run for real with two rank processes on this one card (ZK_BENCH_BACKEND=gloo: RCCL refuses two ranks on one GPU;
+    the driver's scaling run uses RCCL on a whole node).  Small shape so that it takes seconds."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29677", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--inflight", "2",
+                          "--log-n", "16", "--no-pcie", "--no-cpu-baseline", "--no-profile"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["units_per_step_per_gpu"] == 2
