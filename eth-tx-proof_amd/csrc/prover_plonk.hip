@@ -54,7 +54,7 @@ static int32_t plonk_circuit_check(const zk_stark_config *cfg, const zk_plonk_ci
         const u32 ops[2] = {in.a, in.b};
         for (int s = 0; s < (in.op <= ZK_OP_MUL ? 2 : 1); s++) {
             const u32 k = ops[s] >> 24, i = ops[s] & 0xFFFFFFu;
-            const bool ok = k == ZK_OPND_REG ? i < g->n_regs : k == ZK_OPND_LOCAL ? i < c->num_wires + c->num_constants : k == ZK_OPND_CONST ? i < g->n_constants : false;
+            const bool ok = k == ZK_OPND_REG ? i < g->n_regs : k == ZK_OPND_LOCAL ? i < c->num_wires + c->num_constants : k == ZK_OPND_CONST ? i < g->n_constants : k == ZK_OPND_PUBLIC ? i < 4 : false;
             if (!ok) return ZK_ERR_INVALID_ARG;
         }
         if (in.op <= ZK_OP_MUL && ((in.dst >> 24) || (in.dst & 0xFFFFFFu) >= g->n_regs)) return ZK_ERR_INVALID_ARG;
@@ -185,6 +185,7 @@ struct PlkQuotParams {
     const u64 *xA, *xB;                    // x_i = g w_L^i
     const u64 *kis, *bg, *alphas;
     const zk_instr *instrs; const u64 *gconst;
+    const u64 *pih;                        // public_inputs_hash (4 words): the PUBLIC operand of the gate program (PublicInputGate)
     u64 zh_inv[8];
     size_t L; u32 lgL, W, NC, R, NZ, qdf, nchunks, nch, n_instrs, n_regs;
     u64 *out;                              // [challenge][leaf position]
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void plonk_quotient_kernel(PlkQuotParams p) {
         const u32 k = o >> 24, idx = o & 0xFFFFFFu;
         if (k == ZK_OPND_REG) return regs[idx * 256 + t];
         if (k == ZK_OPND_LOCAL) return idx < p.W ? p.w_lde[(size_t)idx * p.L + s] : p.cs_lde[(size_t)(idx - p.W) * p.L + s];
+        if (k == ZK_OPND_PUBLIC) return p.pih[idx];
         return p.gconst[idx];
     };
     for (u32 pc = 0; pc < p.n_instrs; pc++) {
@@ -432,7 +434,7 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
             const u64 gn = gl_pow(GL_GEN, n), wr = gl_root(cfg.rate_bits);
             for (u32 i = 0; i < qdf; i++) qp.zh_inv[i] = gl_inv(gl_sub(gl_mul(gn, gl_pow(wr, i)), 1));
             qp.L = L; qp.lgL = lgL; qp.W = W; qp.NC = NC; qp.R = R; qp.NZ = NZ; qp.qdf = qdf; qp.nchunks = nchunks; qp.nch = nch;
-            qp.n_instrs = st->n_instrs; qp.n_regs = st->n_regs; qp.out = d_qv;
+            qp.n_instrs = st->n_instrs; qp.n_regs = st->n_regs; qp.out = d_qv; qp.pih = d_pih;
             ZK_LAUNCH(ctx, "plonk_quotient", plonk_quotient_kernel, g1(L), dim3(256), (size_t)st->n_regs * 256 * sizeof(u64), qp);
             // coset_ifft(g): leaf-order values -> natural-order coefficients, scaled by L^-1 g^-j; in place
             TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);

@@ -14,7 +14,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._abi import Air, HelperDesc, Instr, OP_ADD, OP_EMIT, OP_MUL, OP_SUB, OPND_CONST, OPND_LOCAL, OPND_REG, opnd, u32, u64
+from ._abi import Air, HelperDesc, Instr, OP_ADD, OP_EMIT, OP_MUL, OP_SUB, OPND_CONST, OPND_LOCAL, OPND_PUBLIC, OPND_REG, opnd, u32, u64
 from .air import AirProgram
 
 P = 0xFFFFFFFF00000001
@@ -50,15 +50,19 @@ def _root(k):
     return _pow(7277203076849721926, 1 << (32 - k))
 
 
-def synthetic_circuit(degree_bits=12, num_wires=135, num_routed=80, n_muladd=16, n_sbox=8, seed=1):
-    """Returns (Circuit, wires) with wires a (num_wires, n) uint64 witness satisfying gates and copy constraints."""
+def synthetic_circuit(degree_bits=12, num_wires=135, num_routed=80, n_muladd=16, n_sbox=8, seed=1, public_input_gate=False):
+    """Returns (Circuit, wires) with wires a (num_wires, n) uint64 witness satisfying gates and copy constraints.
+    public_input_gate: adds upstream's PublicInputGate -- four advice wires whose row-0 cells must equal the four words of
+    public_inputs_hash (PUBLIC operands 0..3), filtered by a selector column that is 1 in row 0.  The witness then depends on the public
+    inputs: `bind_public_inputs(circuit, wires, public_inputs_hash)` writes the four cells (Circuit.pi_wires names the columns)."""
     n = 1 << degree_bits
     rng = np.random.default_rng(seed)
 
     def rand(shape):
         a = rng.integers(0, 1 << 63, size=shape, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=shape, dtype=np.uint64)
         return np.where(a >= np.uint64(P), a - np.uint64(P), a)
-    assert num_routed % 8 == 0 and num_routed <= num_wires and num_wires - num_routed >= n_muladd + n_sbox
+    n_pi = 4 if public_input_gate else 0
+    assert num_routed % 8 == 0 and num_routed <= num_wires and num_wires - num_routed >= n_muladd + n_sbox + n_pi
     # ---- permutation: cell (j, r) -> (j2, r2); sigma_j(w^r) = k_{j2} * w^{r2}, k_j = g^j
     col = np.tile(np.arange(num_routed, dtype=np.int64)[:, None], (1, n))
     row = np.tile(np.arange(n, dtype=np.int64)[None, :], (num_routed, 1))
@@ -92,8 +96,11 @@ def synthetic_circuit(degree_bits=12, num_wires=135, num_routed=80, n_muladd=16,
         elif kind in (1, 2):
             wires[j + 1] = wires[j]
     # ---- constants: c0, c1 (arbitrary), selector (0/1)
-    consts = rand((3, n))
+    consts = rand((3 + (1 if public_input_gate else 0), n))
     consts[2] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    if public_input_gate:
+        consts[3] = 0
+        consts[3][0] = 1
     W = num_wires
     Lc = lambda i: opnd(OPND_LOCAL, i)
     R = lambda i: opnd(OPND_REG, i)
@@ -115,22 +122,39 @@ def synthetic_circuit(degree_bits=12, num_wires=135, num_routed=80, n_muladd=16,
         wires[e] = np.array([pow(int(x), 7, P) for x in wires[a]], dtype=np.uint64)
         ins += [(OP_MUL, 0, Lc(a), Lc(a)), (OP_MUL, 1, R(0), Lc(a)), (OP_MUL, 0, R(0), R(0)), (OP_MUL, 0, R(0), R(1)),   # a^2, a^3, a^4, a^7
                 (OP_SUB, 0, R(0), Lc(e)), (OP_MUL, 0, R(0), Lc(W + 2)), (OP_EMIT, 0, R(0), 0)]
-    gates = AirProgram(W + 3, 0, [], [1], ins, 2)
-    return Circuit(degree_bits, num_wires, num_routed, consts, sig, gates), np.ascontiguousarray(wires, dtype=np.uint64)
+    pi_wires = []
+    for k in range(n_pi):       # PublicInputGate: sel_pi * (wire - public_inputs_hash[k])
+        c_ = adv; adv += 1
+        pi_wires.append(c_)
+        ins += [(OP_SUB, 0, Lc(c_), opnd(OPND_PUBLIC, k)), (OP_MUL, 0, R(0), Lc(W + 3)), (OP_EMIT, 0, R(0), 0)]
+    gates = AirProgram(W + consts.shape[0], 0, [], [1], ins, 2)
+    circ = Circuit(degree_bits, num_wires, num_routed, consts, sig, gates)
+    circ.pi_wires = pi_wires
+    return circ, np.ascontiguousarray(wires, dtype=np.uint64)
+
+
+def bind_public_inputs(circuit, wires, public_inputs_hash):
+    """The witness of a circuit with a PublicInputGate for THESE public inputs: a copy of `wires` with the gate's four row-0 cells set
+    to the words of public_inputs_hash = hash_no_pad(public_inputs)."""
+    w = np.array(wires, dtype=np.uint64, copy=True)
+    for k, col in enumerate(circuit.pi_wires):
+        w[col, 0] = np.uint64(int(public_inputs_hash[k]))
+    return w
 
 
 class SyntheticRecursion:
     """STAND-IN for the recursion circuits (ops.RecursionCircuits) so that the reference's caller shape
     map(&TxProof) -> fold(&AggProof) -> BlockProof (/root/reference/leader/src/prover.rs:26-36) can run end to end on the GPU Plonk
     prover.  NOT recursion: the circuits are `synthetic_circuit`s of the recursion config's shape and do not verify their children;
-    a child is bound to its parent only through the parent's public inputs, which are the Poseidon digests (hash_no_pad, on the
-    GPU) of the children's proof words.  The real aggregation / block circuits are data a maintainer supplies the same way."""
+    a child is bound to its parent through the parent's public inputs -- the Poseidon digests (hash_no_pad, on the GPU) of the
+    children's proof words -- which the circuits constrain with upstream's PublicInputGate (their witness carries
+    public_inputs_hash in the gate's wires).  The real aggregation / block circuits are data a maintainer supplies the same way."""
 
     def __init__(self, cfg=None, degree_bits=12, seed=1):
         from ._abi import standard_recursion_config
         self.cfg = cfg or standard_recursion_config()
-        self.circuits = {"agg": synthetic_circuit(degree_bits=degree_bits, seed=seed),
-                         "block": synthetic_circuit(degree_bits=degree_bits, seed=seed + 1)}
+        self.circuits = {"agg": synthetic_circuit(degree_bits=degree_bits, seed=seed, public_input_gate=True),
+                         "block": synthetic_circuit(degree_bits=degree_bits, seed=seed + 1, public_input_gate=True)}
         self._states = {}
 
     def state(self, ctx, kind):
@@ -145,11 +169,16 @@ class SyntheticRecursion:
     def digest(ctx, words):
         return ctx.hash_rows(np.ascontiguousarray(words, dtype=np.uint64)[None, :])[0]
 
+    def witness(self, ctx, kind, pubs):
+        """The circuit's witness for these public inputs: the PublicInputGate's wires carry hash_no_pad(public inputs)."""
+        circ, wires = self.circuits[kind]
+        return bind_public_inputs(circ, wires, self.digest(ctx, pubs))
+
     def aggregation(self, ctx, lhs, rhs):
         pubs = np.concatenate([self.digest(ctx, lhs.proof), self.digest(ctx, rhs.proof)])
-        return self.state(ctx, "agg"), self.circuits["agg"][1], pubs
+        return self.state(ctx, "agg"), self.witness(ctx, "agg", pubs), pubs
 
     def block(self, ctx, prev, agg, height=1):
         prev_d = self.digest(ctx, prev) if prev is not None else np.zeros(4, dtype=np.uint64)
         pubs = np.concatenate([np.array([height], dtype=np.uint64), self.digest(ctx, agg.proof), prev_d])
-        return self.state(ctx, "block"), self.circuits["block"][1], pubs
+        return self.state(ctx, "block"), self.witness(ctx, "block", pubs), pubs

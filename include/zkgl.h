@@ -362,7 +362,8 @@ int32_t zk_fri_commit_free(zk_fri_commit *s);
  *   quotient chunks commit -> zeta -> OpeningSet -> PolynomialBatch::prove_openings over the four oracles
  *   (constants_sigmas, wires, zs_partial_products, quotient; batches at zeta and at g*zeta for the Zs).
  * Gate program: zk_air with n_trace_cols = num_wires + num_constants (LOCAL index i < num_wires = wire i, else constant column
- * i - num_wires), ops ADD / SUB / MUL / EMIT only, no NEXT / PUBLIC / CHALLENGE operands, n_helpers = 0.
+ * i - num_wires), ops ADD / SUB / MUL / EMIT only, no NEXT / CHALLENGE operands, n_helpers = 0; PUBLIC index i < 4 = word i of
+ * public_inputs_hash = hash_no_pad(public_inputs) -- what upstream's PublicInputGate constrains its wires against.
  *
  * Proof words: "ZKGLPLK1", degree_bits, num_wires, num_routed, num_constants, wires_cap, zs_partial_products_cap, quotient_cap,
  *   openings: constants[NC x2] sigmas[R x2] wires[W x2] zs[nch x2] zs_next[nch x2] partial_products[nch*npp x2]

@@ -37,14 +37,14 @@ static int fri_arities_p_checked(const zk_stark_config *cfg, uint32_t degree_bit
 static void fri_arities_p(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) { (void)fri_arities_p_checked(cfg, degree_bits, out, n_out); }
 
 /* gate program over the base field: LOCAL i < W is wire i, otherwise constant column i - W.  Emitted terms are appended to out. */
-static uint32_t gates_base(const zk_air *g, const uint64_t *wires, const uint64_t *consts, uint32_t W, uint64_t *regs, uint64_t *out) {
+static uint32_t gates_base(const zk_air *g, const uint64_t *wires, const uint64_t *consts, uint32_t W, const uint64_t *pih, uint64_t *regs, uint64_t *out) {
     uint32_t n_out = 0;
     for (uint32_t p = 0; p < g->n_instrs; p++) {
         const zk_instr *in = &g->instrs[p];
         uint64_t v[2]; uint32_t ops[2] = {in->a, in->b};
         for (int s = 0; s < 2; s++) {
             uint32_t k = ops[s] >> 24, i = ops[s] & 0xFFFFFF;
-            v[s] = k == ZK_OPND_REG ? regs[i] : k == ZK_OPND_LOCAL ? (i < W ? wires[i] : consts[i - W]) : k == ZK_OPND_CONST ? gl_canon(g->constants[i]) : 0;
+            v[s] = k == ZK_OPND_REG ? regs[i] : k == ZK_OPND_LOCAL ? (i < W ? wires[i] : consts[i - W]) : k == ZK_OPND_CONST ? gl_canon(g->constants[i]) : k == ZK_OPND_PUBLIC ? pih[i] : 0;
             if (in->op > ZK_OP_MUL) break;
         }
         if (in->op <= ZK_OP_MUL) regs[in->dst & 0xFFFFFF] = in->op == ZK_OP_ADD ? gl_add(v[0], v[1]) : in->op == ZK_OP_SUB ? gl_sub(v[0], v[1]) : gl_mul(v[0], v[1]);
@@ -52,14 +52,14 @@ static uint32_t gates_base(const zk_air *g, const uint64_t *wires, const uint64_
     }
     return n_out;
 }
-static uint32_t gates_ext(const zk_air *g, const gl2 *wires, const gl2 *consts, uint32_t W, gl2 *regs, gl2 *out) {
+static uint32_t gates_ext(const zk_air *g, const gl2 *wires, const gl2 *consts, uint32_t W, const uint64_t *pih, gl2 *regs, gl2 *out) {
     uint32_t n_out = 0;
     for (uint32_t p = 0; p < g->n_instrs; p++) {
         const zk_instr *in = &g->instrs[p];
         gl2 v[2]; uint32_t ops[2] = {in->a, in->b};
         for (int s = 0; s < 2; s++) {
             uint32_t k = ops[s] >> 24, i = ops[s] & 0xFFFFFF;
-            v[s] = k == ZK_OPND_REG ? regs[i] : k == ZK_OPND_LOCAL ? (i < W ? wires[i] : consts[i - W]) : k == ZK_OPND_CONST ? gl2_from(g->constants[i]) : gl2_from(0);
+            v[s] = k == ZK_OPND_REG ? regs[i] : k == ZK_OPND_LOCAL ? (i < W ? wires[i] : consts[i - W]) : k == ZK_OPND_CONST ? gl2_from(g->constants[i]) : k == ZK_OPND_PUBLIC ? gl2_from(pih[i]) : gl2_from(0);
             if (in->op > ZK_OP_MUL) break;
         }
         if (in->op <= ZK_OP_MUL) regs[in->dst & 0xFFFFFF] = in->op == ZK_OP_ADD ? gl2_add(v[0], v[1]) : in->op == ZK_OP_SUB ? gl2_sub(v[0], v[1]) : gl2_mul(v[0], v[1]);
@@ -81,7 +81,7 @@ static int circuit_ok(const zk_stark_config *cfg, const zk_plonk_circuit *c) {
         uint32_t ops[2] = {in->a, in->b};
         for (int s = 0; s < (in->op <= ZK_OP_MUL ? 2 : 1); s++) {
             uint32_t k = ops[s] >> 24, i = ops[s] & 0xFFFFFF;
-            if (k == ZK_OPND_REG ? i >= c->gates->n_regs : k == ZK_OPND_LOCAL ? i >= c->num_wires + c->num_constants : k == ZK_OPND_CONST ? i >= c->gates->n_constants : 1) return 0;
+            if (k == ZK_OPND_REG ? i >= c->gates->n_regs : k == ZK_OPND_LOCAL ? i >= c->num_wires + c->num_constants : k == ZK_OPND_CONST ? i >= c->gates->n_constants : k == ZK_OPND_PUBLIC ? i >= 4 : 1) return 0;
         }
         if (in->op <= ZK_OP_MUL && (in->dst >> 24 || (in->dst & 0xFFFFFF) >= c->gates->n_regs)) return 0;
     }
@@ -217,7 +217,7 @@ int32_t orc_prove_plonk(const zk_stark_config *cfg, orc_plonk_state *st, const u
                         uint64_t next = cidx == nchunks - 1 ? zn[ci] : zr[nch + ci * npp + cidx];
                         terms[t++] = gl_sub(gl_mul(prev, num), gl_mul(next, den));
                     }
-                t += gates_base(c->gates, wr, cr, W, regs, terms + t);
+                t += gates_base(c->gates, wr, cr, W, pih, regs, terms + t);
                 for (uint32_t j = 0; j < nch; j++) {
                     uint64_t acc = 0;
                     for (uint32_t u = t; u-- > 0;) acc = gl_add(gl_mul(acc, alphas[j]), terms[u]);
@@ -449,7 +449,7 @@ int32_t orc_verify_plonk(const zk_stark_config *cfg, const orc_plonk_state *st, 
                 terms[t++] = gl2_sub(gl2_mul(prev, num), gl2_mul(next, den));
             }
         free(kis);
-        t += gates_ext(c->gates, wv, cv, W, regs, terms + t);
+        t += gates_ext(c->gates, wv, cv, W, pih, regs, terms + t);
         for (uint32_t j = 0; j < nch; j++) {
             gl2 acc = {0, 0};
             for (uint32_t u = t; u-- > 0;) acc = gl2_add(gl2_scale(acc, alphas[j]), terms[u]);

@@ -65,7 +65,6 @@ static int fri_arities_checked(const zk_stark_config *cfg, uint32_t degree_bits,
     *n_out = k;
     return ok;
 }
-static void fri_arities(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) { (void)fri_arities_checked(cfg, degree_bits, out, n_out); }
 
 #define FAIL(code) do { rc = (code); goto done; } while (0)
 

@@ -72,7 +72,7 @@ def test_prover_input_map_fold_block(orc):
 
         def combine(a, b):
             pubs = np.concatenate([dig(a), dig(b)])
-            rc, p = orc.prove_plonk(agg_state, rec.circuits["agg"][1], pubs)
+            rc, p = orc.prove_plonk(agg_state, plonk.bind_public_inputs(*rec.circuits["agg"], dig(pubs)), pubs)
             assert rc == 0 and orc.verify_plonk(agg_state, pubs, p) == 0
             return p
         level = proofs
@@ -82,7 +82,7 @@ def test_prover_input_map_fold_block(orc):
                 nxt.append(level[-1])
             level = nxt
         pubs = np.concatenate([np.array([1], dtype=np.uint64), dig(level[0]), np.zeros(4, dtype=np.uint64)])
-        rc, ref = orc.prove_plonk(blk_state, rec.circuits["block"][1], pubs)
+        rc, ref = orc.prove_plonk(blk_state, plonk.bind_public_inputs(*rec.circuits["block"], dig(pubs)), pubs)
         assert rc == 0
         assert block.b_height == 1 and (block.intern == ref).all()
         assert orc.verify_plonk(blk_state, pubs, block.intern) == 0

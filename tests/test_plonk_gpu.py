@@ -110,3 +110,27 @@ def test_plonk_more_than_sixteen_chunks_is_refused(ctx, zk):
     with pytest.raises(zk.ZkError) as e:
         zk.PlonkState(ctx, _cfg(), circ)
     assert e.value.code == -1
+
+
+def test_public_input_gate_binds_the_proof_to_its_public_inputs(ctx, zk, orc):
+    """A circuit with upstream's PublicInputGate (PUBLIC operands = the words of public_inputs_hash): same proof as the oracle, accepted;
+    the same proof under other public inputs, and a witness that does not carry the hash, are rejected."""
+    from eth_tx_proof_amd import plonk
+    cfg = _cfg()
+    circ, wires = plonk.synthetic_circuit(degree_bits=8, seed=21, public_input_gate=True)
+    pub = np.array([11, 22, 33, 44, 55], dtype=np.uint64)
+    pih = ctx.hash_rows(pub[None, :])[0]
+    assert (pih == orc.hash_rows(pub[None, :])[0]).all()
+    w = plonk.bind_public_inputs(circ, wires, pih)
+    ost = orc.PlonkState(cfg, circ)
+    st = zk.PlonkState(ctx, cfg, circ)
+    try:
+        proof = zk.prove_plonk(st, w, pub)
+        rc, ref = orc.prove_plonk(ost, w, pub)
+        assert rc == 0 and (proof == ref).all()
+        assert orc.verify_plonk(ost, pub, proof) == 0
+        other = pub.copy(); other[0] += np.uint64(1)
+        assert orc.verify_plonk(ost, other, proof) != 0
+        assert orc.verify_plonk(ost, pub, zk.prove_plonk(st, wires, pub)) != 0          # witness without the hash in the gate's wires
+    finally:
+        st.free()
