@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """One-off parity run beyond what the test suite does: the unit proof at 2^LOG_N rows x 93 (+40) columns (default 23, north_star's
 target shape) on the GPU against the oracle's proof of the same trace, word for word.  The oracle needs about 5 KB of host memory per
-row and minutes of CPU time, so this is a tool, not a test: it refuses to start without enough free memory and prints a heartbeat
-while the oracle runs.  usage: python tools/parity_big.py [log_n] > result.json"""
+row and minutes of CPU time, so it runs outside the default suite (tests/test_gpu_big.py, ZK_TEST_BIG=1): it refuses to start without
+enough free memory and prints a heartbeat while the oracle runs.  usage: python tests/parity_big.py [log_n] > result.json"""
 import json, os, sys, threading, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ -> repo root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import eth_tx_proof_amd as E
