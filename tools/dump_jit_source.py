@@ -1,6 +1,6 @@
 import os, sys
 os.environ["ZK_QUOTIENT_JIT"]="2"; os.environ["ZK_QUOTIENT_JIT_DUMP"]="gpurun_out/quotient_jit_93.hip"
-sys.path.insert(0, "."); sys.path.insert(0, "oracle")
+sys.path.insert(0, ".")
 import numpy as np
 import eth_tx_proof_amd as E
 from eth_tx_proof_amd import lib as zk, air
