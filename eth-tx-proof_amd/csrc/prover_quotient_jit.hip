@@ -77,7 +77,78 @@ struct Gen {
     }
 };
 
+// Wide AIRs (thousands of instructions): ONE straight-line function makes hipcc's time grow with the square of its length (430 columns /
+// 2 191 instructions: 79 s; 2 431 columns / 10 195: more than half an hour).  Above JIT_CHUNK_MIN instructions the program is cut into
+// chunks of JIT_CHUNK instructions, each a separate non-inlined device function that takes the few values alive at a cut -- the
+// program's registers (at most 24 by the bytecode's own rule), the accumulators, the row's selectors -- through memory and loads the
+// columns it touches itself.  Compile time becomes linear (2 431 columns: about a minute), the run-time cost is a few dozen scratch
+// accesses per chunk.
+#define JIT_CHUNK_MIN 1536u
+#define JIT_CHUNK 256u
+static std::string generate_chunked(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname, bool standalone) {
+    std::string s;
+    if (standalone) {
+        s += "#include \"gl64.cuh\"\n";
+        s += "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u32 *redo; u32 redo_cap; u32 pad; };\n";
+    }
+    const u32 NR = air->n_regs ? air->n_regs : 1;
+    u32 n_chunks = 0;
+    for (u32 pc0 = 0; pc0 < air->n_instrs; pc0 += JIT_CHUNK, n_chunks++) {
+        Gen g; g.air = air; g.C = C; g.A = A;
+        g.have_l.assign(C + A, 0); g.have_n.assign(C + A, 0); g.have_pub.assign(air->n_public_inputs + 1, 0);
+        const u32 pc1 = pc0 + JIT_CHUNK < air->n_instrs ? pc0 + JIT_CHUNK : air->n_instrs;
+        for (u32 pc = pc0; pc < pc1; pc++) {
+            const zk_instr &in = air->instrs[pc];
+            std::string a = g.opnd(in.a);
+            if (in.op <= ZK_OP_MUL) {
+                std::string b = g.opnd(in.b);
+                appendf(g.body, "    r%u = %s(%s, %s);\n", in.dst & 0xFFFFFF, in.op == ZK_OP_ADD ? "gl_add" : in.op == ZK_OP_SUB ? "gl_sub" : "g.mul", a.c_str(), b.c_str());
+            } else {
+                const char *f = in.op == ZK_OP_EMIT_TRANSITION ? "z_last" : in.op == ZK_OP_EMIT_FIRST ? "l_first" : in.op == ZK_OP_EMIT_LAST ? "l_last" : nullptr;
+                if (f) appendf(g.body, "    { const u64 c = g.mul(%s, %s);", a.c_str(), f);
+                else appendf(g.body, "    { const u64 c = %s;", a.c_str());
+                for (u32 j = 0; j < nch; j++) appendf(g.body, " acc%u = g.mul_add(acc%u, al%u, c);", j, j, j);
+                g.body += " }\n";
+            }
+        }
+        appendf(s, "template <bool EX> __device__ __noinline__ u64 %s_c%u(const u64 *__restrict__ trace_lde, const u64 *__restrict__ aux_lde, const u64 *__restrict__ pubv, "
+                   "const u64 *__restrict__ chalv, u64 L_, u64 s, u64 sn, u64 z_last, u64 l_first, u64 l_last, const u64 *al_, u64 *r_, u64 *acc_) {\n", kname, n_chunks);
+        s += "    glx<EX> g; g.fl = 0;\n";
+        s += "    const struct { const u64 *trace_lde, *aux_lde, *pub, *chal; u64 L; } p = {trace_lde, aux_lde, pubv, chalv, L_};\n";
+        for (u32 r = 0; r < NR; r++) appendf(s, "    u64 r%u = r_[%u];\n", r, r);
+        for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = acc_[%u]; const u64 al%u = al_[%u];\n", j, j, j, j);
+        s += g.body;
+        for (u32 r = 0; r < NR; r++) appendf(s, "    r_[%u] = r%u;\n", r, r);
+        for (u32 j = 0; j < nch; j++) appendf(s, "    acc_[%u] = acc%u;\n", j, j);
+        s += "    return g.fl;\n}\n";
+    }
+    appendf(s, "template <bool EX> __device__ __forceinline__ u64 %s_run(const QJitParams &p, u64 s, u32 i, u64 sn) {\n", kname);
+    s += "    glx<EX> g; g.fl = 0;\n";
+    s += "    const u64 x = g.mul(p.xA[i & 2047], p.xB[i >> 11]);\n    const u64 z_last = gl_sub(x, p.last_inv);\n";
+    s += "    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];\n";
+    appendf(s, "    u64 rr[%u], ac[%u], alv[%u];\n", NR, nch, nch);
+    for (u32 r = 0; r < NR; r++) appendf(s, "    rr[%u] = 0;\n", r);
+    for (u32 j = 0; j < nch; j++) appendf(s, "    ac[%u] = 0; alv[%u] = p.alphas[%u];\n", j, j, j);
+    s += "    u64 fl = 0;\n";
+    for (u32 k = 0; k < n_chunks; k++)
+        appendf(s, "    fl |= %s_c%u<EX>(p.trace_lde, p.aux_lde, p.pub, p.chal, p.L, s, sn, z_last, l_first, l_last, alv, rr, ac);\n", kname, k);
+    s += "    u64 zi = p.zh_inv[0];\n";
+    appendf(s, "    { const u32 zsel = i & %uu;\n", (1u << rate_bits) - 1);
+    for (u32 j = 1; j < (1u << rate_bits); j++) appendf(s, "      zi = zsel == %uu ? p.zh_inv[%u] : zi;\n", j, j);
+    s += "    }\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = g.mul(ac[%u], zi);\n", j, j);
+    s += "    return g.fl | fl;\n}\n";
+    appendf(s, "extern \"C\" __global__ __launch_bounds__(256) void %s(QJitParams p) {\n", kname);
+    s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
+    s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
+    appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
+    appendf(s, "    const u64 f = %s_run<false>(p, s, i, sn);\n", kname);
+    appendf(s, "    if ((f != 0) | p.force) %s_run<true>(p, s, i, sn);\n}\n", kname);
+    return s;
+}
+
 std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname = "quotient_jit", bool standalone = true) {
+    if (air->n_instrs >= JIT_CHUNK_MIN) return generate_chunked(air, C, A, nch, rate_bits, kname, standalone);
     Gen g; g.air = air; g.C = C; g.A = A;
     g.have_l.assign(C + A, 0); g.have_n.assign(C + A, 0); g.have_pub.assign(air->n_public_inputs + 1, 0);
     for (u32 pc = 0; pc < air->n_instrs; pc++) {
@@ -156,12 +227,12 @@ extern "C" int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_cha
     return ZK_OK;
 }
 
-// mode -1: never; 0 (default): only kernels compiled ahead of time by zk_prover_state_prepare; 1: compile at first use for tables
-// with >= 2^min_log coset points; 2: compile at first use, always
+// mode -1: never; 0 (default): only kernels compiled ahead of time (with the library, or by zk_prover_state_prepare / loaded from the
+// prover-state directory); 1: also compile at first use for tables with >= 2^min_log coset points; 2: compile at first use, always.
+// A kernel that EXISTS is used at any table size: only compiling at first use is gated by the size.
 bool zk_quotient_jit_enabled(const zk_ctx *ctx, size_t L) {
-    if (ctx->quotient_jit_mode == 2 || ctx->quotient_aot) return true;   // kernels built with the library cost nothing to use: any size
-    if (L < ((size_t)1 << ctx->quotient_jit_min_log)) return false;
-    return ctx->quotient_jit_mode >= 0;
+    (void)L;
+    return ctx->quotient_jit_mode >= 0 || ctx->quotient_aot;
 }
 
 static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k);
@@ -182,9 +253,9 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
         }
     }
     if (ctx->quotient_jit_mode < 0) return ZK_JIT_UNAVAILABLE;
-    if (ctx->quotient_jit_mode != 2 && p.L < ((size_t)1 << ctx->quotient_jit_min_log)) return ZK_JIT_UNAVAILABLE;   // too small to pay for hiprtc
+    const bool worth_compiling = ctx->quotient_jit_mode == 2 || (ctx->quotient_jit_mode == 1 && p.L >= ((size_t)1 << ctx->quotient_jit_min_log));
     JitKernel k;
-    int32_t rc = jit_get(ctx, air, C, A, nch, rate_bits, ctx->quotient_jit_mode >= 1, k);
+    int32_t rc = jit_get(ctx, air, C, A, nch, rate_bits, worth_compiling, k);
     if (rc != ZK_OK) return rc;
     if (!k.fn) return ZK_JIT_UNAVAILABLE;
     void *args[] = {&p};
@@ -207,8 +278,6 @@ extern "C" int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *c
         const zk_air *air = tables[t].air;
         if (!air) return ZK_ERR_INVALID_ARG;
         if (zk_air_validate(air, cfg->num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "prover_state_prepare: malformed AIR");
-        const size_t L = (size_t)1 << (tables[t].log_n + cfg->rate_bits);
-        if (!zk_quotient_jit_enabled(ctx, L)) continue;
         const u32 nch = cfg->num_challenges, A = zk_air_n_aux(air, nch);
         if (ctx->quotient_aot && zk_quotient_aot_lookup(fnv1a(air_key(air, air->n_trace_cols, A, nch, cfg->rate_bits)))) continue;   // built with the library
         JitKernel k;
@@ -281,7 +350,7 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
             // device-independent (the code object is per architecture); tied to the generator and to the field header it compiles
             // against, so a library upgrade never runs a stale kernel
             std::string disk_key = air_key(air, C, A, nch, rate_bits);
-            { const u64 ver[2] = {2 /* generator version */, fnv1a(GL64_SRC)}; disk_key.append((const char *)ver, sizeof ver); }
+            { const u64 ver[2] = {3 /* generator version */, fnv1a(GL64_SRC)}; disk_key.append((const char *)ver, sizeof ver); }
             k.image = std::make_shared<std::vector<char>>();
             const bool from_disk = co_load(disk_key, *k.image);
             std::string src = from_disk ? std::string() : generate(air, C, A, nch, rate_bits);

@@ -187,10 +187,11 @@ def test_fri_instance_error_paths(ctx, zk):
     assert zk.fri_prove_instance(ctx, cfg, [b], [((5, 6), [(0, 0), (0, 2)])], c).size > 0
 
 
-@pytest.mark.parametrize("n_cols,n_helpers,log_n", [(6, 2, 7), (93, 19, 9), (7, 0, 8), (21, 5, 10)])
+@pytest.mark.parametrize("n_cols,n_helpers,log_n", [(6, 2, 7), (93, 19, 9), (7, 0, 8), (21, 5, 10), (430, 19, 6)])
 def test_quotient_jit_equals_interpreter_and_oracle(zk, orc, monkeypatch, n_cols, n_helpers, log_n):
     """the constraint program compiled with hiprtc (ZK_QUOTIENT_JIT=2: always) and the bytecode interpreter (=0) produce the
-    oracle's quotient polynomials bit for bit"""
+    oracle's quotient polynomials bit for bit.  (430 columns = 2 191 instructions: the generator cuts programs of that length into
+    chunks, one non-inlined function each.)"""
     from eth_tx_proof_amd import air
     cfg = _cfg()
     rng = np.random.default_rng(log_n)

@@ -12,6 +12,7 @@ from eth_tx_proof_amd import air, lib as zl
 ap = argparse.ArgumentParser()
 ap.add_argument("--inflight", type=int, default=4)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--jit", action="store_true", help="compile the constraint kernels of all seven tables first (zk_prover_state_prepare; minutes for the wide ones)")
 args = ap.parse_args()
 cfg = E.standard_fast_config()
 
@@ -27,6 +28,10 @@ def unit(ctx):
 
 ctxs = [zl.Context(0) for _ in range(max(1, args.inflight))]
 units = [unit(c) for c in ctxs]
+if args.jit:
+    t0 = time.time()
+    zl.prover_state_prepare(ctxs[0], cfg, units[0])
+    print("prover state prepared (constraint kernels compiled / loaded) in %.1f s: %s" % (time.time() - t0, zl.prover_state_stats()), flush=True)
 first = zl.prove_tables(ctxs[0], cfg, units[0])
 for c, u in zip(ctxs[1:], units[1:]):
     assert np.array_equal(zl.prove_tables(c, cfg, u), first)        # same seeds: every context must produce the same proof
