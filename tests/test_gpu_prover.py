@@ -418,3 +418,27 @@ def test_cfg4_all_seven_tables_at_their_real_sizes_bit_exact(ctx, zk, orc):
         bad = np.nonzero(proof != ref)[0]
         pytest.fail("first differing word %d of %d" % (bad[0], proof.size))
     assert orc.verify(cfg, [(p, lg, None, pub) for p, lg, _, pub in items], proof) == 0
+
+
+def test_cfg4_with_prepared_constraint_kernels_bit_exact(zk, orc):
+    """The seven-table unit again, this time with the prover state prepared (zk_prover_state_prepare: hiprtc compiles the constraint
+    kernels of the three wide tables -- 430, 523 and 2 431 columns, generated in chunks, about a minute and a half when nothing is
+    cached -- the narrow ones were built with the library): every table's quotient comes from compiled code, and the proof is still the
+    oracle's, word for word."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    c2 = zk.Context(0)
+    try:
+        items = []
+        for t, (w, lg) in enumerate(zip(air.ZKEVM_TABLE_WIDTHS, air.ZKEVM_CFG4_LOG_SIZES)):
+            prog = air.cpu_like_air(w, min(19, w // 4))
+            tr, pub = orc.synth_trace(w, lg, 0x5EED0000 + 1000 * t)
+            items.append((prog, lg, tr, pub))
+        zk.prover_state_prepare(c2, cfg, items)
+        c2.profile(True); c2.profile_reset()
+        proof = zk.prove_tables(c2, cfg, items)
+        assert c2.profile_report()["quotient_eval"][0] == 7
+        rc, ref = orc.prove(cfg, items)
+        assert rc == 0 and proof.size == ref.size and (proof == ref).all()
+    finally:
+        c2.close()
