@@ -435,6 +435,7 @@ def test_cfg4_with_prepared_constraint_kernels_bit_exact(zk, orc):
             tr, pub = orc.synth_trace(w, lg, 0x5EED0000 + 1000 * t)
             items.append((prog, lg, tr, pub))
         zk.prover_state_prepare(c2, cfg, items)
+        assert sum(zk.prover_state_stats()) >= 3            # compiled now, or loaded from the prover-state directory
         c2.profile(True); c2.profile_reset()
         proof = zk.prove_tables(c2, cfg, items)
         assert c2.profile_report()["quotient_eval"][0] == 7
