@@ -11,19 +11,22 @@
 //     (tools/gen_constants.py derive_wave): lane k accumulates "x0 before round k", lanes 32..43 the final state, and a round is
 //     readlane(x0) -> s-box on the uniform value -> ONE multiply-add per lane against the lane's coefficient of u_q.
 //     No cross-lane reduction at all (the 16-lane version spends 4 shuffle+add stages per round on its dot product).
-// Tables: PSD_WV_INIT[12][64], PSD_WV_CHAIN[22][64], PSD_WV_MDS[12][64] (23 KB), staged in LDS by the caller (fill()).
+// Tables: PSD_WV_INIT[12][64], PSD_WV_CHAIN[22][64] (lane 63 = the round's constant K), PSD_WV_MDS[12][64], PSD_WV_RC[9][64] (the
+// per-lane constants of the full rounds and PR_FIRST) -- 28 KB, staged in LDS by the caller (fill()): every constant the dependent
+// chain needs arrives by a prefetched ds_read, none by a global or scalar load in the middle of the chain.
 #pragma once
 #include "poseidon.cuh"
 
 namespace psdw {
 
-constexpr int TAB_WORDS = (12 + 22 + 12) * 64;      // 23 KB
+constexpr int TAB_WORDS = (12 + 22 + 12 + 9) * 64;      // 28 KB
 
 // all threads of the block copy the two tables into `lds` (TAB_WORDS u64); caller synchronises afterwards
 __device__ __forceinline__ void fill(u64 *lds) {
     for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lds[i] = PSD_WV_INIT[i];
     for (int i = threadIdx.x; i < 22 * 64; i += blockDim.x) lds[12 * 64 + i] = PSD_WV_CHAIN[i];
     for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lds[34 * 64 + i] = PSD_WV_MDS[i];
+    for (int i = threadIdx.x; i < 9 * 64; i += blockDim.x) lds[46 * 64 + i] = PSD_WV_RC[i];
 }
 
 __device__ __forceinline__ u64 rdlane64(u64 v, int l) {
@@ -48,9 +51,13 @@ template <bool EXACT> struct perm {
 
     // four full rounds starting at `round`; weak in (lanes 0..11), weak out, idle lanes come out 0
     __device__ __forceinline__ u64 full_rounds(u64 s, int round) {
+        const auto *rcrow = tab + 46 * 64 + (round ? 4 * 64 : 0) + lane;
+        u64 rcn = rcrow[0];
 #pragma unroll 1
         for (int r = 0; r < 4; r++) {
-            s = pc.sbox(psd::wadd_c(s, PSD_RC[12 * (round + r) + lc]));
+            const u64 rc = rcn;
+            rcn = rcrow[64 * (r < 3 ? r + 1 : 3)];
+            s = pc.sbox(psd::wadd_c(s, rc));
             const u32 lo = (u32)s, hi = (u32)(s >> 32);
             u64 al = 0, ah = 0;
 #pragma unroll
@@ -72,7 +79,7 @@ template <bool EXACT> struct perm {
     __device__ __forceinline__ u64 run(u64 s) {
         s = full_rounds(s, 0);
         // ---- 22 partial rounds
-        const u64 z = psd::wadd_c(s, PSD_PR_FIRST[lc]);
+        const u64 z = psd::wadd_c(s, tab[46 * 64 + 8 * 64 + lane]);
         u64 acc;
         {
             psd::acc3 a; a.init();
@@ -87,7 +94,7 @@ template <bool EXACT> struct perm {
             const u64 c = cnext;
             cnext = ch[64 * (q < 21 ? q + 1 : 21)];
             const u64 x0 = rdlane64(acc, q);
-            const u64 u = psd::wadd_c(pc.sbox(x0), PSD_PR_K[q]);
+            const u64 u = psd::wadd_c(pc.sbox(x0), rdlane64(c, 63));
             acc = pc.mul_add(c, u, acc);
         }
         // final state sits in lanes 32..43

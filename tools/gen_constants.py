@@ -135,6 +135,10 @@ def derive_wave(tabs):
             T_init[i][32 + j] = init[j - 1][i - 1]
         for q in range(R_P):
             T_chain[q][32 + j] = wcol[q][j - 1]
+    # lane 63 of a chain row carries K[q] (an idle lane: its accumulator is never read), so the round's constant arrives with the
+    # round's coefficients instead of through a scalar load in the middle of the dependent chain
+    for q in range(R_P):
+        T_chain[q][63] = k[q]
     return T_init, T_chain
 
 
@@ -153,7 +157,8 @@ def poseidon_wave(state, tabs, wave):
     z = [(s[i] + first[i]) % P for i in range(12)]
     acc = [sum(T_init[i][ln] * z[i] for i in range(12)) % P for ln in range(64)]
     for q in range(R_P):
-        u = (pow(acc[q], 7, P) + k[q]) % P
+        assert T_chain[q][63] == k[q]
+        u = (pow(acc[q], 7, P) + T_chain[q][63]) % P
         acc = [(acc[ln] + T_chain[q][ln] * u) % P for ln in range(64)]
     s = [acc[32 + j] for j in range(12)]
     r += R_P
@@ -219,6 +224,9 @@ def main():
         Mfull = S.mds_matrix()
         assert all(mds[i][l] == Mfull[l][i] for i in range(12) for l in range(12)) and all(S.MDS_DIAG[i] == 0 for i in range(1, 12))
         f.write(c_array("PSD_WV_MDS", [x for row in mds for x in row], per_line=8, qual="PSD_CONST"))
+        # per-lane constants of the eight full rounds (rows 0..3: rounds 0..3, rows 4..7: rounds 26..29) and PR_FIRST as row 8
+        wrc = [[RC[12 * rnd + l] if l < 12 else 0 for l in range(64)] for rnd in (0, 1, 2, 3, 26, 27, 28, 29)] + [[first[l] if l < 12 else 0 for l in range(64)]]
+        f.write(c_array("PSD_WV_RC", [x for row in wrc for x in row], per_line=8, qual="PSD_CONST"))
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     with open(os.path.join(ROOT, "tests", "golden", "poseidon_rc.json"), "w") as f:
         json.dump({"sha256_le_u64": hashlib.sha256(b"".join(struct.pack("<Q", c) for c in RC)).hexdigest(),
