@@ -162,10 +162,20 @@ int32_t zk_pow_search_dev(zk_ctx *ctx, u32 min_zeros, u64 *d_pow_state) {
     // expected 2^min_zeros candidates; 2^(min_zeros+6) of them fail with probability e^-64.  Later blocks exit early
     // once a smaller witness is recorded.
     u64 total = (u64)1 << (min_zeros + 6 > 40 ? 40 : min_zeros + 6);
-    u64 per_launch = (u64)1 << 17;          // later launches exit at their first instruction once a witness is known
-    for (u64 base = 0; base < total; base += per_launch) {
-        u64 cnt = total - base < per_launch ? total - base : per_launch;
-        ZK_LAUNCH(ctx, "pow_grind", pow_grind_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, d_pow_state, base, min_zeros);
+    // Launches grow: the first covers 4 x the expected search (misses with probability e^-4), the next 16 x, the last the rest.  A
+    // later launch costs its blocks one load each once a witness is known -- three launches instead of 32 equal ones, which were 2 ms
+    // of launch latency per seven-table unit.
+    u64 base = 0;
+    const u64 first = (u64)1 << (min_zeros + 2), second = (u64)1 << (min_zeros + 4);
+    const u64 cuts[3] = {first < total ? first : total, second < total ? second : total, total};
+    for (int k = 0; k < 3; k++) {
+        if (cuts[k] <= base) continue;
+        u64 cnt = cuts[k] - base;
+        while (cnt) {                                            // a launch is at most 2^31 - 256 blocks
+            const u64 c = cnt < ((u64)1 << 38) ? cnt : ((u64)1 << 38);
+            ZK_LAUNCH(ctx, "pow_grind", pow_grind_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, d_pow_state, base, min_zeros);
+            base += c; cnt -= c;
+        }
     }
     return ZK_OK;
 }
