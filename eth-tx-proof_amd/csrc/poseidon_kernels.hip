@@ -169,6 +169,45 @@ __global__ __launch_bounds__(256, 3) void fri_leaf_hash_mfma_kernel(const PsdmTa
         }
     }
 }
+// Small commits (fewer leaves than would give every SIMD a matrix-core wave): the sponge of ONE leaf is a serial chain of
+// ceil(C/8) permutations, and one thread per leaf walks it at ~60 us per permutation.  Here a leaf gets 16 lanes (poseidon_coop.cuh,
+// ~20 us per permutation, up to 8192 leaves) or a whole wave (poseidon_wave.cuh, ~10 us, up to 1024 leaves): word l of the state in
+// lane l, lanes 0..7 fetch the next eight columns.  430 columns x 2^10 leaves: 3.4 -> 0.6 ms.
+template <bool WAVE> __global__ __launch_bounds__(256) void hash_leaves_colmajor_small_kernel(const u64 *__restrict__ cols, size_t stride, u32 n_cols,
+                                                                                              size_t n_leaves, u64 *__restrict__ out, u64 force_redo) {
+    __shared__ u64 wtab[WAVE ? psdw::TAB_WORDS : 1];
+    if (WAVE) { psdw::fill(wtab); __syncthreads(); }
+    const int lane = threadIdx.x & 63, l = WAVE ? lane : (lane & 15), gb = lane & ~15;
+    const size_t leaf = WAVE ? (size_t)blockIdx.x * 4 + (threadIdx.x >> 6) : ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = leaf < n_leaves;
+    u64 s = 0;
+    for (u32 c0 = 0; c0 < n_cols; c0 += 8) {
+        if (live && l < 8 && c0 + l < n_cols) s = cols[(size_t)(c0 + l) * stride + leaf];
+        s = WAVE ? psdw::permute(s, lane, wtab, force_redo) : psdc::permute16(s, l, gb);
+        if (l >= 12) s = 0;
+    }
+    if (live && l < 4) out[4 * leaf + l] = s;
+}
+// the same for the leaves of a FRI commit-phase layer (`arity` extension values flattened [a0,b0,a1,b1,...])
+template <bool WAVE> __global__ __launch_bounds__(256) void fri_leaf_hash_small_kernel(const u64 *__restrict__ re, const u64 *__restrict__ im, size_t n_leaves,
+                                                                                       u32 arity, u64 *__restrict__ out, u64 force_redo) {
+    __shared__ u64 wtab[WAVE ? psdw::TAB_WORDS : 1];
+    if (WAVE) { psdw::fill(wtab); __syncthreads(); }
+    const int lane = threadIdx.x & 63, l = WAVE ? lane : (lane & 15), gb = lane & ~15;
+    const size_t leaf = WAVE ? (size_t)blockIdx.x * 4 + (threadIdx.x >> 6) : ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = leaf < n_leaves;
+    u64 s = 0;
+    for (u32 w0 = 0; w0 < 2 * arity; w0 += 8) {
+        const u32 w = w0 + (u32)l;
+        if (live && l < 8 && w < 2 * arity) s = ((w & 1) ? im : re)[leaf * arity + (w >> 1)];
+        s = WAVE ? psdw::permute(s, lane, wtab, force_redo) : psdc::permute16(s, l, gb);
+        if (l >= 12) s = 0;
+    }
+    if (live && l < 4) out[4 * leaf + l] = s;
+}
+#define PSD_SMALL_WAVE_MAX 1024u      // leaves: one wave per leaf up to here (one wave per SIMD), 16 lanes per leaf up to PSD_SMALL_COOP_MAX
+#define PSD_SMALL_COOP_MAX 8192u
+
 // device copy of the matrix-core tables: built on the host once per process, one copy per device shared by all contexts,
 // uploaded with a blocking hipMemcpy under a lock (complete before any launch that uses it can be enqueued)
 static const PsdmTables *psdm_tables(zk_ctx *ctx) {
@@ -333,6 +372,16 @@ int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uin
                   n_leaves, digests, ctx->force_redo);
         return ZK_OK;
     }
+    if (n_cols > 4 && !(ctx->poseidon_mfma & 8)) {       // bit 3 of ZK_POSEIDON_MFMA: no lane-cooperative kernels (thread per leaf instead)
+        if (n_leaves <= PSD_SMALL_WAVE_MAX) {
+            ZK_LAUNCH(ctx, label, hash_leaves_colmajor_small_kernel<true>, dim3((unsigned)((n_leaves + 3) / 4)), dim3(256), 0, cols, stride, n_cols, n_leaves, digests, ctx->force_redo);
+            return ZK_OK;
+        }
+        if (n_leaves <= PSD_SMALL_COOP_MAX) {
+            ZK_LAUNCH(ctx, label, hash_leaves_colmajor_small_kernel<false>, grid1(n_leaves * 16), dim3(256), 0, cols, stride, n_cols, n_leaves, digests, ctx->force_redo);
+            return ZK_OK;
+        }
+    }
     ZK_LAUNCH(ctx, label, hash_leaves_colmajor_kernel, grid1(n_leaves), dim3(256), 0, cols, stride, n_cols, n_leaves, digests, ctx->force_redo);
     return ZK_OK;
 }
@@ -342,7 +391,15 @@ int32_t zk_hash_leaves_rowmajor(zk_ctx *ctx, const u64 *rows, uint32_t leaf_len,
 }
 // true when the matrix-core kernel took the launch (big layers whose arity is a multiple of four); false: caller uses its own kernel
 bool zk_fri_leaf_hash_mfma(zk_ctx *ctx, const u64 *re, const u64 *im, size_t n_leaves, uint32_t arity, u64 *digests) {
-    if (!(ctx->poseidon_mfma & 1) || n_leaves < PSDM_MIN_UNITS || n_leaves % 256 != 0 || arity % 4 != 0 || arity * 2 <= 4) return false;
+    if (arity * 2 <= 4) return false;                                       // hash_or_noop's copy branch: the caller's kernel
+    if (!(ctx->poseidon_mfma & 8) && n_leaves <= PSD_SMALL_COOP_MAX) {      // small layers: a wave / 16 lanes per leaf (see above)
+        if (n_leaves <= PSD_SMALL_WAVE_MAX)
+            ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_small_kernel<true>, dim3((unsigned)((n_leaves + 3) / 4)), dim3(256), 0, re, im, n_leaves, arity, digests, ctx->force_redo);
+        else
+            ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_small_kernel<false>, grid1(n_leaves * 16), dim3(256), 0, re, im, n_leaves, arity, digests, ctx->force_redo);
+        return true;
+    }
+    if (!(ctx->poseidon_mfma & 1) || n_leaves < PSDM_MIN_UNITS || n_leaves % 256 != 0 || arity % 4 != 0) return false;
     const PsdmTables *T = psdm_tables(ctx);
     if (!T) return false;
     ZK_LAUNCH(ctx, "fri_leaf_hash", fri_leaf_hash_mfma_kernel, dim3((unsigned)(n_leaves / 256)), dim3(256), 0, T, re, im, n_leaves, arity, digests, ctx->force_redo);

@@ -12,6 +12,7 @@ from eth_tx_proof_amd import air, lib as zl
 ap = argparse.ArgumentParser()
 ap.add_argument("--inflight", type=int, default=4)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--top", type=int, default=12)
 ap.add_argument("--jit", action="store_true", help="compile the constraint kernels of all seven tables first (zk_prover_state_prepare; minutes for the wide ones)")
 args = ap.parse_args()
 cfg = E.standard_fast_config()
@@ -43,7 +44,7 @@ for _ in range(args.reps):
 dt = (time.time() - t0) / args.reps
 ctx.profile(False)
 print("cfg4 unit alone: %.2f ms, proof %d words" % (dt * 1e3, p.size))
-for k, (l, ms) in sorted(ctx.profile_report().items(), key=lambda kv: -kv[1][1])[:12]:
+for k, (l, ms) in sorted(ctx.profile_report().items(), key=lambda kv: -kv[1][1])[:args.top]:
     print("  %-28s %5d launches %8.3f ms/unit" % (k, l // args.reps, ms / args.reps))
 if args.inflight > 1:
     def work(c, u):
