@@ -75,6 +75,38 @@ template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_pair(const Psdm
     }
     return pm.pc.fl;
 }
+// 32 leaves per wave (psdm::perm<.., 1>): for commits of 16384 .. 65535 leaves, where the pair layout would leave SIMDs without a wave
+template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_single(const PsdmTables *__restrict__ T, const u64 *__restrict__ cols, size_t stride,
+                                                                        u32 n_cols, size_t leaf0, u32 lane, const psdm_v4i *lds, u64 (&s)[1][6]) {
+    psdm::perm<EXACT, 1> pm; pm.init(T, lane, lds);
+    const u32 n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 6; i++) s[0][i] = 0;
+    for (u32 c0 = 0; c0 < n_cols; c0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const u32 w = 6 * h + i;
+            if (w < 8 && c0 + w < n_cols) s[0][i] = cols[(size_t)(c0 + w) * stride + leaf0 + n];
+        }
+        pm.run(s);
+    }
+    return pm.pc.fl;
+}
+__global__ __launch_bounds__(256, 3) void hash_leaves_colmajor_mfma32_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ cols, size_t stride,
+                                                                            u32 n_cols, size_t n_leaves, u64 *__restrict__ out, u64 force_redo) {
+    const u32 lane = threadIdx.x & 63;
+    const size_t leaf0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;                 // n_leaves is a multiple of 128
+    __shared__ psdm_v4i shA[PSDM_LDS_V4];
+    psdm::lds_fill(T, shA); __syncthreads();
+    u64 s[1][6];
+    if (leaf_sponge_single<false>(T, cols, stride, n_cols, leaf0, lane, shA, s) | force_redo)
+        leaf_sponge_single<true>(T, cols, stride, n_cols, leaf0, lane, shA, s);
+    if (lane < 32) {
+        ulonglong2 *o = (ulonglong2 *)(out + 4 * (leaf0 + lane));
+        o[0] = make_ulonglong2(s[0][0], s[0][1]);
+        o[1] = make_ulonglong2(s[0][2], s[0][3]);
+    }
+}
 __global__ __launch_bounds__(256, 3) void hash_leaves_colmajor_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ cols, size_t stride,
                                                                           u32 n_cols, size_t n_leaves, u64 *__restrict__ out, u64 force_redo) {
     const u32 lane = threadIdx.x & 63;
@@ -368,8 +400,12 @@ int32_t zk_hash_leaves_colmajor(zk_ctx *ctx, const u64 *cols, size_t stride, uin
     if ((ctx->poseidon_mfma & 1) && n_cols > 4 && n_leaves >= PSDM_MIN_UNITS && n_leaves % 256 == 0) {
         const PsdmTables *T = psdm_tables(ctx);
         if (!T) return ZK_ERR_OOM;
-        ZK_LAUNCH(ctx, label, hash_leaves_colmajor_mfma_kernel, dim3((unsigned)(n_leaves / 256)), dim3(256), 0, T, cols, stride, n_cols,
-                  n_leaves, digests, ctx->force_redo);
+        if (n_leaves < 65536 && !(ctx->poseidon_mfma & 16))      // fewer pair-layout waves than SIMDs: 32 leaves per wave (bit 4 of the switch: off)
+            ZK_LAUNCH(ctx, label, hash_leaves_colmajor_mfma32_kernel, dim3((unsigned)(n_leaves / 128)), dim3(256), 0, T, cols, stride, n_cols,
+                      n_leaves, digests, ctx->force_redo);
+        else
+            ZK_LAUNCH(ctx, label, hash_leaves_colmajor_mfma_kernel, dim3((unsigned)(n_leaves / 256)), dim3(256), 0, T, cols, stride, n_cols,
+                      n_leaves, digests, ctx->force_redo);
         return ZK_OK;
     }
     if (n_cols > 4 && !(ctx->poseidon_mfma & 8)) {       // bit 3 of ZK_POSEIDON_MFMA: no lane-cooperative kernels (thread per leaf instead)

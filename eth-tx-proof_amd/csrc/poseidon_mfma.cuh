@@ -112,7 +112,9 @@ __device__ __forceinline__ void swap32(u64 &vdst, u64 &src) {
     vdst = ((u64)hi[0] << 32) | lo[0]; src = ((u64)hi[1] << 32) | lo[1];
 }
 
-template <bool EXACT> struct perm {
+// NC = permutations per lane pair: 2 = pair layout (64 permutations per wave), 1 = 32 permutations per wave (lane (n, h) holds words
+// 6h..6h+5 of permutation n only) -- half the vector work per wave, for launches too small to give every SIMD a pair-layout wave.
+template <bool EXACT, int NC = 2> struct perm {
     psd::core<EXACT> pc;
     const __attribute__((address_space(1))) PsdmTables *T;     // typed as global memory: global_load with a scalar base, not flat_load
     u32 lane;
@@ -122,10 +124,10 @@ template <bool EXACT> struct perm {
     __device__ __forceinline__ void init(const PsdmTables *tab, u32 lane_, const psdm_v4i *lds) { T = (const __attribute__((address_space(1))) PsdmTables *)tab; lane = lane_; pc.fl = 0; K.init(); Alds = (psdm_lds_ptr)lds; }
 
     // s <- MDS * s + constants of layer `layer`
-    __device__ __forceinline__ void mds(u64 (&s)[2][6], int layer) {
-        psdm_v4i b[2][3];
+    __device__ __forceinline__ void mds(u64 (&s)[NC][6], int layer) {
+        psdm_v4i b[NC][3];
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < NC; c++)
 #pragma unroll
             for (int k = 0; k < 3; k++) b[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
 #pragma unroll
@@ -133,7 +135,7 @@ template <bool EXACT> struct perm {
             const psdm_v16i cin = ld16l(Alds + PSDM_LDS_CMDS + ((layer * 3 + t) * 2 + (lane >> 5)) * 4);
             const psdm_v4i a0 = Alds[(3 * t + 0) * 64 + lane], a1 = Alds[(3 * t + 1) * 64 + lane], a2 = Alds[(3 * t + 2) * 64 + lane];
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < NC; c++) {
                 psdm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[c][0], cin, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[c][1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b[c][2], acc, 0, 0, 0);
@@ -141,11 +143,11 @@ template <bool EXACT> struct perm {
             }
         }
     }
-    __device__ __forceinline__ void full_rounds(u64 (&s)[2][6], int layer0) {
+    __device__ __forceinline__ void full_rounds(u64 (&s)[NC][6], int layer0) {
 #pragma unroll 1
         for (int r = 0; r < 4; r++) {
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < NC; c++)
 #pragma unroll
                 for (int i = 0; i < 6; i++) s[c][i] = pc.sbox(s[c][i]);
             mds(s, layer0 + r);
@@ -158,15 +160,16 @@ template <bool EXACT> struct perm {
     // one k-step per finished block; the vector ALU only adds the in-block feedback (0 + 1 + 2 + 3 products per block instead of
     // q products in round q: 31 instead of 210 per permutation).  The chain itself runs one permutation per lane (lane (n, h) runs
     // permutation (c = h, n)); matrix-core operands and results are in pair layout, two v_permlane32_swap exchanges per word.
-    __device__ __forceinline__ void partial_rounds(u64 (&s)[2][6]) {
-        psdm_v4i bs[2][3];                 // operand bytes of the state; the state registers themselves are free from here on
+    __device__ __forceinline__ void partial_rounds(u64 (&s)[NC][6]) {
+        psdm_v4i bs[NC][3];                // operand bytes of the state; the state registers themselves are free from here on
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < NC; c++)
 #pragma unroll
             for (int k = 0; k < 3; k++) bs[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
-        psdm_v4i by[2][6];                 // operand bytes of the finished blocks' s-box outputs
+        psdm_v4i by[NC][6];                // operand bytes of the finished blocks' s-box outputs
         u64 x;
-        { u64 d = s[0][0], w = s[1][0]; swap32(d, w); x = d; }
+        // (NC = 1: both lane halves run the chain of permutation n -- a copy, not garbage, so that the sticky word stays as rare)
+        { u64 d = s[0][0], w = s[NC - 1][0]; swap32(d, w); x = d; }
         const u64 *Dm = PSD_PR_D, *Kc = PSD_PR_K;
 #pragma unroll
         for (int b = 0; b < 6; b++) {
@@ -179,11 +182,12 @@ template <bool EXACT> struct perm {
                 for (int k = 0; k < 3 + b; k++) {
                     const psdm_v4i a = ld4(&T->A_F[b][k][lane][0]);
                     acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[1][k] : by[1][k - 3], acc1, 0, 0, 0);
+                    if (NC == 2) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1, 0, 0, 0);
                 }
                 u64 f0[2], f1[2];
                 recombine2(K, acc0, f0[0], f0[1]);
-                recombine2(K, acc1, f1[0], f1[1]);
+                if (NC == 2) recombine2(K, acc1, f1[0], f1[1]);
+                else { f1[0] = f0[0]; f1[1] = f0[1]; }
 #pragma unroll
                 for (int i = 0; i < 2; i++) { u64 yy = f0[i], xx = f1[i]; swap32(yy, xx); F[i] = yy; F[2 + i] = xx; }
             }
@@ -211,7 +215,8 @@ template <bool EXACT> struct perm {
             {
                 u64 v0 = y[0], s0 = y[2], v1 = y[1], s1 = y[3];
                 swap32(v0, s0); swap32(v1, s1);
-                by[0][b] = bfrag(v0, v1); by[1][b] = bfrag(s0, s1);
+                by[0][b] = bfrag(v0, v1);
+                if (NC == 2) by[NC - 1][b] = bfrag(s0, s1);
             }
         }
         // ---- exit map G2 (K = 12 state words + 6 blocks of y), + RC[26]
@@ -223,28 +228,28 @@ template <bool EXACT> struct perm {
             for (int k = 0; k < 9; k++) {
                 const psdm_v4i a = ld4(&T->A_G2[t][k][lane][0]);
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[1][k] : by[1][k - 3], acc1, 0, 0, 0);
+                if (NC == 2) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1, 0, 0, 0);
             }
             recombine2(K, acc0, s[0][2 * t], s[0][2 * t + 1]);
-            recombine2(K, acc1, s[1][2 * t], s[1][2 * t + 1]);
+            if (NC == 2) recombine2(K, acc1, s[NC - 1][2 * t], s[NC - 1][2 * t + 1]);
         }
     }
 
     // any 64-bit representatives in, canonical out
-    __device__ __forceinline__ void run(u64 (&s)[2][6]) {
+    __device__ __forceinline__ void run(u64 (&s)[NC][6]) {
         // the table pointers are made opaque once per permutation: otherwise hipcc hoists the (loop-invariant) operand and
         // accumulator-start loads of every layer out of the caller's loop and keeps ~100 registers alive for them
         asm volatile("" : "+s"(T), "+v"(Alds));
         {
             const auto *rc0 = T->RC_first + 6 * (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < 6; i++) { const u64 k = rc0[i]; s[0][i] = psd::wadd_c(s[0][i], k); s[1][i] = psd::wadd_c(s[1][i], k); }
+            for (int i = 0; i < 6; i++) { const u64 k = rc0[i]; s[0][i] = psd::wadd_c(s[0][i], k); if (NC == 2) s[NC - 1][i] = psd::wadd_c(s[NC - 1][i], k); }
         }
         full_rounds(s, 0);
         partial_rounds(s);
         full_rounds(s, 4);
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+        for (int c = 0; c < NC; c++)
 #pragma unroll
             for (int i = 0; i < 6; i++) s[c][i] = gl_canon(s[c][i]);
     }
