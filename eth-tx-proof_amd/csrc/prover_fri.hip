@@ -80,6 +80,52 @@ __global__ __launch_bounds__(256) void fri_combine_kernel(CombineParams p) {
     }
 }
 
+// The same for small tables (n <= 2^16: fewer waves than SIMDs, and a thread walking thousands of columns is a long serial chain):
+// 8 threads share a position, each takes an eighth of the columns, partial sums meet in LDS.  Field addition is exact, so the order
+// of the summation does not show in the result.
+__global__ __launch_bounds__(256) void fri_combine_split_kernel(CombineParams p) {
+    __shared__ u64 part[4][8][32];
+    const u32 t = threadIdx.x, lp = t & 31, slice = t >> 5;
+    const size_t pos = (size_t)blockIdx.x * 32 + lp;
+    const bool live = pos < p.n;
+    const u32 total = p.cnt[0] + p.cnt[1] + p.cnt[2], per = (total + 7) / 8, lo = slice * per, hi = lo + per < total ? lo + per : total;
+    u64 ra = 0, rb = 0, p1a = 0, p1b = 0;
+    u32 j0 = 0;
+    for (int sgi = 0; sgi < 3; sgi++) {
+        const u32 cnt = p.cnt[sgi];
+        const u32 c0 = lo > j0 ? lo - j0 : 0, c1 = hi > j0 ? (hi - j0 < cnt ? hi - j0 : cnt) : 0;
+        if (live && c0 < c1) {
+            const u64 *base = p.seg[sgi] + pos;
+            u64 sa = 0, sb = 0;
+            for (u32 c = c0; c < c1; c++) {
+                const u64 v = base[(size_t)c * p.n];
+                sa = gl_add(sa, gl_mul(v, p.apow[2 * (j0 + c)]));
+                sb = gl_add(sb, gl_mul(v, p.apow[2 * (j0 + c) + 1]));
+            }
+            ra = gl_add(ra, sa); rb = gl_add(rb, sb);
+            if (sgi < 2) { p1a = gl_add(p1a, sa); p1b = gl_add(p1b, sb); }         // batch g*zeta = trace | aux prefix
+        }
+        j0 += cnt;
+    }
+    part[0][slice][lp] = ra; part[1][slice][lp] = rb; part[2][slice][lp] = p1a; part[3][slice][lp] = p1b;
+    __syncthreads();
+    if (slice == 0 && live) {
+        u64 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { acc[k] = part[k][0][lp]; for (int q = 1; q < 8; q++) acc[k] = gl_add(acc[k], part[k][q][lp]); }
+        p.P[pos] = acc[0]; p.P[p.n + pos] = acc[1]; p.P[2 * p.n + pos] = acc[2]; p.P[3 * p.n + pos] = acc[3];
+        if (p.nch && p.cnt[1]) {
+            u64 za = 0, zb = 0;
+            const u64 *zc = p.seg[1] + (size_t)(p.cnt[1] - p.nch) * p.n + pos;
+            for (u32 k = 0; k < p.nch; k++) {
+                u64 v = zc[(size_t)k * p.n];
+                za = gl_add(za, gl_mul(v, p.apow[2 * k])); zb = gl_add(zb, gl_mul(v, p.apow[2 * k + 1]));
+            }
+            p.P[4 * p.n + pos] = za; p.P[5 * p.n + pos] = zb;
+        }
+    }
+}
+
 // PrecomputedReducedOpenings: y_b = sum_j alpha^j opening_j per batch, read from the proof buffer
 __global__ void reduce_openings_kernel(const u64 *proof, FriLayout lay, u32 C, u32 A, u32 Q, u32 nch, const u64 *apow, u64 *y) {
     __shared__ u64 red[2 * 256];
@@ -269,7 +315,8 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     CombineParams cp = {};
     cp.seg[0] = trace->coeffs; cp.cnt[0] = C; cp.seg[1] = aux ? aux->coeffs : nullptr; cp.cnt[1] = A; cp.seg[2] = quot->coeffs; cp.cnt[2] = Q;
     cp.nch = nch; cp.n = n; cp.apow = d_apow; cp.P = P;
-    ZK_LAUNCH(ctx, "fri_combine", fri_combine_kernel, g1(n), dim3(256), 0, cp);
+    if (n <= ((size_t)1 << 16)) ZK_LAUNCH(ctx, "fri_combine", fri_combine_split_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, cp);
+    else ZK_LAUNCH(ctx, "fri_combine", fri_combine_kernel, g1(n), dim3(256), 0, cp);
     for (u32 par = 0; rc == ZK_OK && par < (1u << rate_bits); par++) {
         u64 shift = gl_mul(GL_GEN, gl_pow(gl_root(lgL), par));
         TwoLevel pre = zk_scale_table(ctx, shift, 1, log_n);
