@@ -37,13 +37,17 @@ first = zl.prove_tables(ctxs[0], cfg, units[0])
 for c, u in zip(ctxs[1:], units[1:]):
     assert np.array_equal(zl.prove_tables(c, cfg, u), first)        # same seeds: every context must produce the same proof
 ctx = ctxs[0]
+t0 = time.time()
+for _ in range(args.reps):
+    p = zl.prove_tables(ctx, cfg, units[0])
+print("cfg4 unit alone, profiler off: %.2f ms" % ((time.time() - t0) / args.reps * 1e3))
 ctx.profile(True); ctx.profile_reset()
 t0 = time.time()
 for _ in range(args.reps):
     p = zl.prove_tables(ctx, cfg, units[0])
 dt = (time.time() - t0) / args.reps
 ctx.profile(False)
-print("cfg4 unit alone: %.2f ms, proof %d words" % (dt * 1e3, p.size))
+print("cfg4 unit alone, hipEvent profiler on: %.2f ms, proof %d words" % (dt * 1e3, p.size))
 for k, (l, ms) in sorted(ctx.profile_report().items(), key=lambda kv: -kv[1][1])[:args.top]:
     print("  %-28s %5d launches %8.3f ms/unit" % (k, l // args.reps, ms / args.reps))
 if args.inflight > 1:
