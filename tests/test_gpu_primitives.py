@@ -260,7 +260,8 @@ def test_matrix_core_poseidon_equals_vector_alu_and_oracle(zk, orc, monkeypatch,
     rng = np.random.default_rng(log_n * 100 + ncols)
     vals = field_rand(rng, (ncols, 1 << log_n))
     o = orc.Batch(vals, rate_bits=rate_bits, cap_height=4)
-    for mode, redo in (("3", "0"), ("0", "0"), ("3", "1"), ("1", "0"), ("2", "0")):
+    # 19 = 3 | 16: pair layout (64 leaves per wave) also below 65536 leaves; 11 = 3 | 8: no lane-cooperative small kernels
+    for mode, redo in (("3", "0"), ("0", "0"), ("3", "1"), ("1", "0"), ("2", "0"), ("19", "0"), ("19", "1"), ("11", "0")):
         monkeypatch.setenv("ZK_POSEIDON_MFMA", mode)
         monkeypatch.setenv("ZK_FORCE_EXACT_REDO", redo)
         c = zk.Context(0)
@@ -297,3 +298,24 @@ def test_matrix_core_poseidon_rare_repair_rows(zk, orc, monkeypatch):
             b.free()
         finally:
             c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,ncols,rate_bits", [(9, 430, 1), (8, 71, 1), (12, 93, 1), (11, 523, 1), (5, 9, 1), (10, 5, 0), (6, 135, 3)])
+def test_small_commit_kernels_equal_thread_per_leaf_and_oracle(zk, orc, monkeypatch, log_n, ncols, rate_bits):
+    """Commits of fewer than 16384 leaves: a wave per leaf (up to 1024 leaves), 16 lanes per leaf (up to 8192), one thread per leaf
+    (ZK_POSEIDON_MFMA bit 3) -- with and without the forced exact redo -- all give the oracle's cap and digests."""
+    rng = np.random.default_rng(1000 + log_n + ncols)
+    vals = field_rand(rng, (ncols, 1 << log_n))
+    o = orc.Batch(vals, rate_bits=rate_bits, cap_height=min(4, log_n + rate_bits))
+    for mode, redo in (("3", "0"), ("11", "0"), ("3", "1")):
+        monkeypatch.setenv("ZK_POSEIDON_MFMA", mode)
+        monkeypatch.setenv("ZK_FORCE_EXACT_REDO", redo)
+        c2 = zk.Context(0)
+        try:
+            b = c2.batch_from_values(vals, rate_bits=rate_bits, cap_height=min(4, log_n + rate_bits))
+            assert (b.cap == o.cap).all(), (mode, redo)
+            assert (b.digests() == o.digests).all(), (mode, redo)
+            b.free()
+        finally:
+            c2.close()
