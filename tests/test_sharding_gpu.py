@@ -89,3 +89,67 @@ def test_bench_two_rank_path_rehearsed_on_one_gpu(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["config"]["units_per_step_per_gpu"] == 2
+
+
+LEADER_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+    import numpy as np, torch.distributed as dist
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import air, leader, ops, plonk, sharding
+    import orc
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    orc.lib().orc_set_threads(8)
+    rec = plonk.SyntheticRecursion(degree_bits=7, seed=5)
+    st = ops.set_prover_state_from_config(0, recursion=rec)
+    prog = air.cpu_like_air(9, 2)
+    units, traces = [], []
+    for u in range(6):                                     # every rank holds the job description (the reference's proof_gen_ir)
+        tr, pub = orc.synth_trace(9, 8, 300 + u)
+        traces.append((tr, pub))
+        units.append(ops.GenerationInputs([ops.TableInput(prog, 8, tr, pub)], txn_number_before=u, block_number=1))
+    block = leader.ProverInput(units).prove(leader.Runtime(num_workers=2), group=sharding.host_group())
+    if rank != 0:
+        assert block is None
+    else:
+        # the same job through the oracle, single process: unit proofs, the balanced fold, the block proof
+        dig = lambda w: orc.hash_rows(np.ascontiguousarray(w)[None, :])[0]
+        level = []
+        for tr, pub in traces:
+            rc, p = orc.prove(st.config, [(prog, 8, tr, pub)])
+            assert rc == 0
+            level.append(p)
+        agg_state = orc.PlonkState(rec.cfg, rec.circuits["agg"][0])
+        blk_state = orc.PlonkState(rec.cfg, rec.circuits["block"][0])
+        def combine(a, b):
+            pubs = np.concatenate([dig(a), dig(b)])
+            rc, p = orc.prove_plonk(agg_state, plonk.bind_public_inputs(*rec.circuits["agg"], dig(pubs)), pubs)
+            assert rc == 0
+            return p
+        while len(level) > 1:
+            nxt = [combine(level[j], level[j + 1]) for j in range(0, len(level) - 1, 2)]
+            if len(level) & 1:
+                nxt.append(level[-1])
+            level = nxt
+        pubs = np.concatenate([np.array([1], dtype=np.uint64), dig(level[0]), np.zeros(4, dtype=np.uint64)])
+        rc, ref = orc.prove_plonk(blk_state, plonk.bind_public_inputs(*rec.circuits["block"], dig(pubs)), pubs)
+        assert rc == 0 and (block.intern == ref).all() and block.b_height == 1
+        assert orc.verify_plonk(blk_state, pubs, block.intern) == 0
+        print("LEADER_OK")
+    dist.barrier()
+    dist.destroy_process_group()
+""") % (ROOT, ROOT)
+
+
+def test_prover_input_prove_over_two_ranks(tmp_path):
+    """leader.ProverInput.prove with the map stage sharded over two rank processes (both on this one card, gloo): units proved where
+    they land, proofs handed to rank 0 over the host group, fold and block proof there -- and the block proof is the one the oracle
+    produces for the whole job in a single process."""
+    script = tmp_path / "leader_worker.py"
+    script.write_text(LEADER_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29688", str(script)], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "LEADER_OK" in out.stdout
