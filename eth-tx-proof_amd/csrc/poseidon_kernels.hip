@@ -143,6 +143,36 @@ template <bool EXACT> __device__ __forceinline__ u64 two_to_one_pair(const PsdmT
     pm.run(s);
     return pm.pc.fl;
 }
+// 32 parents per wave, for levels of 16384 .. 65535 parents (see hash_leaves_colmajor_mfma32_kernel)
+template <bool EXACT> __device__ __forceinline__ u64 two_to_one_single(const PsdmTables *__restrict__ T, const u64 *__restrict__ child, size_t parent0,
+                                                                       u32 lane, const psdm_v4i *lds, u64 (&s)[1][6]) {
+    psdm::perm<EXACT, 1> pm; pm.init(T, lane, lds);
+    const u32 n = lane & 31, h = lane >> 5;
+    const u64 *p = child + 8 * (parent0 + n);
+    if (h == 0) {
+        const ulonglong2 a = ((const ulonglong2 *)p)[0], b = ((const ulonglong2 *)p)[1], d = ((const ulonglong2 *)p)[2];
+        s[0][0] = a.x; s[0][1] = a.y; s[0][2] = b.x; s[0][3] = b.y; s[0][4] = d.x; s[0][5] = d.y;
+    } else {
+        const ulonglong2 e = ((const ulonglong2 *)p)[3];
+        s[0][0] = e.x; s[0][1] = e.y; s[0][2] = 0; s[0][3] = 0; s[0][4] = 0; s[0][5] = 0;
+    }
+    pm.run(s);
+    return pm.pc.fl;
+}
+__global__ __launch_bounds__(256, 3) void merkle_level_mfma32_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ child, u64 *__restrict__ parent,
+                                                                    size_t n_parents, u64 force_redo) {
+    const u32 lane = threadIdx.x & 63;
+    const size_t parent0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;               // n_parents is a multiple of 128
+    __shared__ psdm_v4i shA[PSDM_LDS_V4];
+    psdm::lds_fill(T, shA); __syncthreads();
+    u64 s[1][6];
+    if (two_to_one_single<false>(T, child, parent0, lane, shA, s) | force_redo) two_to_one_single<true>(T, child, parent0, lane, shA, s);
+    if (lane < 32) {
+        ulonglong2 *o = (ulonglong2 *)(parent + 4 * (parent0 + lane));
+        o[0] = make_ulonglong2(s[0][0], s[0][1]);
+        o[1] = make_ulonglong2(s[0][2], s[0][3]);
+    }
+}
 __global__ __launch_bounds__(256, 3) void merkle_level_mfma_kernel(const PsdmTables *__restrict__ T, const u64 *__restrict__ child, u64 *__restrict__ parent,
                                                                   size_t n_parents, u64 force_redo) {
     const u32 lane = threadIdx.x & 63;
@@ -449,8 +479,12 @@ int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap
         if ((ctx->poseidon_mfma & 2) && cnt / 2 >= PSDM_MIN_UNITS && (cnt / 2) % 256 == 0) {
             const PsdmTables *T = psdm_tables(ctx);
             if (!T) return ZK_ERR_OOM;
-            ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_mfma_kernel, dim3((unsigned)(cnt / 2 / 256)), dim3(256), 0, T, (const u64 *)cur, nxt, cnt / 2,
-                      ctx->force_redo);
+            if (cnt / 2 < 65536 && !(ctx->poseidon_mfma & 16))
+                ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_mfma32_kernel, dim3((unsigned)(cnt / 2 / 128)), dim3(256), 0, T, (const u64 *)cur, nxt, cnt / 2,
+                          ctx->force_redo);
+            else
+                ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_mfma_kernel, dim3((unsigned)(cnt / 2 / 256)), dim3(256), 0, T, (const u64 *)cur, nxt, cnt / 2,
+                          ctx->force_redo);
         } else if (cnt / 2 <= 2048 && !(ctx->poseidon_mfma & 8))
             ZK_LAUNCH(ctx, "poseidon_merkle_level_wave", merkle_level_wave_kernel, dim3((unsigned)((cnt / 2 + 3) / 4)), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo);
         else if (cnt / 2 <= 16384)
