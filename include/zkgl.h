@@ -267,8 +267,11 @@ int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tabl
                         uint64_t *proof_out, size_t proof_cap_words, size_t *proof_len_words);
 /* Prover state: what the reference builds once at start-up (common/src/prover_state/mod.rs:59-95, used through
  * ops::p_state, ops/src/lib.rs:16-18).  Here: the constraint programs of the given tables compiled to gfx950 code (hiprtc) and
- * cached for the process; without this call proofs evaluate constraints with the bytecode interpreter.  Call from the thread
- * that created the context, before handing units to worker threads.  `trace` of the tables is not read. */
+ * cached for the process (and in the prover-state directory, zk_prover_state_cache_dir); without this call proofs evaluate
+ * constraints with the bytecode interpreter unless the AIR's kernel was built with the library.  Every table given here is compiled,
+ * whatever its size (programs of thousands of instructions are generated in chunks: minutes at most), and a compiled kernel is used
+ * at any table size afterwards.  Call from the thread that created the context, before handing units to worker threads.  `trace` of
+ * the tables is not read. */
 int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables);
 /* Persistence of the compiled part of the prover state -- the counterpart of the reference's `./prover_state_<digest>` file
  * (/root/reference/common/src/prover_state/persistence.rs:40-88, name from get_configuration_digest,
