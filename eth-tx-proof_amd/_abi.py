@@ -11,7 +11,7 @@ ERRORS = {0: "ZK_OK", -1: "ZK_ERR_INVALID_ARG", -2: "ZK_ERR_OOM", -3: "ZK_ERR_HI
           -9: "ZK_ERR_BUFFER_TOO_SMALL"}
 
 OPND_REG, OPND_LOCAL, OPND_NEXT, OPND_CONST, OPND_PUBLIC, OPND_CHALLENGE = range(6)
-OP_ADD, OP_SUB, OP_MUL, OP_EMIT, OP_EMIT_TRANSITION, OP_EMIT_FIRST, OP_EMIT_LAST = range(7)
+OP_ADD, OP_SUB, OP_MUL, OP_EMIT, OP_EMIT_TRANSITION, OP_EMIT_FIRST, OP_EMIT_LAST, OP_EMIT_SLOT = range(8)
 
 
 def opnd(kind, idx):

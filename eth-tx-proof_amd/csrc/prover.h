@@ -38,8 +38,9 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
 // fri_proof on final values F (2 columns of L, leaf order); only the o_nl..per_query fields of `lay` are used
 int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, u32 log_n, u64 *F, const zk_batch *const *oracles,
                          u32 n_oracles, u64 *d_proof, const FriLayout &lay);
-// prove_openings for any FriInstanceInfo: points on the host (canonical), polynomial lists on the host
-struct FriBatchDesc { u64 point[2]; u32 n_polys; const zk_fri_poly *polys; };
+// prove_openings for any FriInstanceInfo: polynomial lists on the host; a batch's point either on the host (canonical, d_point ==
+// nullptr) or already in HBM (d_point: 2 words, e.g. a challenge the transcript kernel just wrote -- no download in the middle of a proof)
+struct FriBatchDesc { u64 point[2]; u32 n_polys; const zk_fri_poly *polys; const u64 *d_point = nullptr; };
 int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *const *oracles, u32 n_oracles,
                                   const FriBatchDesc *batches, u32 n_batches, u64 *d_proof, const FriLayout &lay);
 

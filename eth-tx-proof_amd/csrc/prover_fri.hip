@@ -462,8 +462,9 @@ __global__ void fri_join_evals_kernel(const u64 *ev, u32 nb, u64 *y) {
     u64 w = gl_add(gl_add(gl_dbl(gl_dbl(b7)), gl_dbl(b7)), b7);
     y[2 * b] = gl_add(e[0], w); y[2 * b + 1] = gl_add(e[1], e[2]);
 }
+__global__ void fri_copy_point_kernel(const u64 *src, u64 *dst) { if (threadIdx.x < 2) dst[threadIdx.x] = src[threadIdx.x]; }
 struct QuotGenParams {
-    const u64 *Pval; size_t L; u32 lgL, nb;
+    const u64 *Pval; size_t L; u32 lgL, nb; u64 *err;
     const u64 *xA, *xB;
     const u64 *pts;           // z_b (2 words each)
     const u64 *y;             // P_b(z_b)
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256) void fri_quotient_gen_kernel(QuotGenParams p) 
         } else { nrm[b] = 1; den[b] = gl2_make(1, 0); num[b] = gl2_make(0, 0); }
         pre[b] = acc; acc = gl_mul(acc, nrm[b]);
     }
+    if (acc == 0) atomicCAS((unsigned long long *)p.err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_ZETA_IN_SUBGROUP);   // x == z_b: a point on the LDE coset
     u64 inv = gl_inv_fermat(acc);
 #pragma unroll
     for (int b = FRI_MAX_BATCHES - 1; b >= 0; b--) {
@@ -527,6 +529,7 @@ int32_t zk_fri_final_values_dev(zk_ctx *ctx, const zk_stark_config &cfg, const u
         }
         gp.cnt = std::max(gp.cnt, batches[b].n_polys);
         gp.sh[b] = batches[b].n_polys;
+        if (batches[b].d_point) continue;        // device-resident point: copied below, checked by the quotient kernel (zero denominator)
         hpts[2 * b] = batches[b].point[0]; hpts[2 * b + 1] = batches[b].point[1];
         // the pointwise quotient needs x != z on the LDE coset g*H_L: only a base-field z with (z/g)^L == 1 can collide
         if (hpts[2 * b + 1] == 0 && gl_pow(gl_mul(hpts[2 * b], gl_inv(GL_GEN)), (u64)L) == 1)
@@ -543,9 +546,11 @@ int32_t zk_fri_final_values_dev(zk_ctx *ctx, const zk_stark_config &cfg, const u
     const u64 **d_cols = (const u64 **)own.get(cols.size() * sizeof(u64 *));
     u64 *P = (u64 *)own.get(2 * nb * n * sizeof(u64)), *Pval = (u64 *)own.get(2 * nb * L * sizeof(u64)), *tmp = (u64 *)own.get(2 * nb * n * sizeof(u64));
     if (!d_apow || !d_pts || !d_ev || !d_y || !d_cols || !P || !Pval || !tmp) return ctx->fail(ZK_ERR_OOM, "fri instance: out of device memory");
-    rc = zk_dev_upload(ctx, d_pts, hpts, sizeof hpts);
-    if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_cols, cols.data(), cols.size() * sizeof(u64 *));
+    rc = ctx->upload_small(d_pts, hpts, sizeof hpts);
+    if (rc == ZK_OK) rc = ctx->upload_small(d_cols, cols.data(), cols.size() * sizeof(u64 *));
     if (rc) return rc;
+    for (u32 b = 0; b < nb; b++)
+        if (batches[b].d_point) ZK_LAUNCH(ctx, "fri_copy_point", fri_copy_point_kernel, dim3(1), dim3(64), 0, batches[b].d_point, d_pts + 2 * b);
     ZK_LAUNCH(ctx, "fri_alpha_pows", alpha_pows_gen_kernel, g1(gp.cnt + FRI_MAX_BATCHES), dim3(256), 0, d_alpha, gp, d_apow);
     cp.cols = d_cols; cp.n = n; cp.apow = d_apow; cp.P = P;
     ZK_LAUNCH(ctx, "fri_combine", fri_combine_gen_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, cp);
@@ -560,7 +565,7 @@ int32_t zk_fri_final_values_dev(zk_ctx *ctx, const zk_stark_config &cfg, const u
     }
     if (rc) return rc;
     QuotGenParams qp = {};
-    qp.Pval = Pval; qp.L = L; qp.lgL = lgL; qp.nb = nb;
+    qp.Pval = Pval; qp.L = L; qp.lgL = lgL; qp.nb = nb; qp.err = ctx->d_err;
     TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
     qp.xA = xs.A; qp.xB = xs.B; qp.pts = d_pts; qp.y = d_y; qp.shifts = d_apow + 2 * gp.cnt; qp.F = F;
     ZK_LAUNCH(ctx, "fri_quotient", fri_quotient_gen_kernel, g1(L), dim3(256), 0, qp);

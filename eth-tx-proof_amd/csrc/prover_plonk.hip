@@ -5,7 +5,7 @@
 // reduce_with_powers), quotient chunks, OpeningSet, PolynomialBatch::prove_openings over the four oracles -- the work the reference
 // does behind /root/reference/ops/src/lib.rs:52 (after the STARK proofs), :72 (AggProof::combine) and :95 (BlockProof::execute)
 // with CircuitConfig::standard_recursion_config() (crate pinned at /root/reference/Cargo.lock:3441-3443).  The circuit is plain data
-// (include/zkgl.h: zk_plonk_circuit); everything except the 16-byte download of zeta stays on the device.
+// (include/zkgl.h: zk_plonk_circuit); everything stays on the device: one host synchronisation per proof (the final download).
 #include <string.h>
 #include "zk_internal.h"
 #include "prover.h"
@@ -35,22 +35,32 @@ struct zk_plonk_state {
     u64 digest[4];
 };
 
+// number of gate constraint terms (zkgl.h): ZK_OP_EMIT writes term (number of EMITs before it), ZK_OP_EMIT_SLOT term `dst`
+static u32 plonk_gate_terms(const zk_air *g) {
+    u32 c = 0, hi = 0;
+    for (u32 p = 0; p < g->n_instrs; p++) {
+        if (g->instrs[p].op == ZK_OP_EMIT) c++;
+        else if (g->instrs[p].op == ZK_OP_EMIT_SLOT && g->instrs[p].dst + 1 > hi) hi = g->instrs[p].dst + 1;
+    }
+    return c > hi ? c : hi;
+}
 static int32_t plonk_circuit_check(const zk_stark_config *cfg, const zk_plonk_circuit *c) {
     if (!cfg || !c || !c->gates || !c->constants || !c->sigmas) return ZK_ERR_INVALID_ARG;
     if (c->degree_bits < 2 || c->degree_bits > 24 || c->num_wires == 0 || c->num_wires > 4096 || c->num_routed_wires == 0 || c->num_routed_wires > c->num_wires ||
         c->num_constants == 0 || c->num_constants > 4096)
         return ZK_ERR_INVALID_ARG;
-    if (cfg->rate_bits == 0 || cfg->rate_bits > 3 || c->quotient_degree_factor != (1u << cfg->rate_bits) || c->num_routed_wires % c->quotient_degree_factor ||
-        c->num_routed_wires / c->quotient_degree_factor > PLK_MAX_CHUNKS)
+    if (cfg->rate_bits == 0 || cfg->rate_bits > 3 || c->quotient_degree_factor != (1u << cfg->rate_bits) || c->num_routed_wires % c->quotient_degree_factor)
         return ZK_ERR_INVALID_ARG;
+    if (c->n_domain_separator > 4096 || (c->n_domain_separator && !c->domain_separator)) return ZK_ERR_INVALID_ARG;
     if (cfg->num_challenges == 0 || cfg->num_challenges > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits < 2 || cfg->fri_arity_bits > 6 || cfg->num_query_rounds == 0 ||
         cfg->proof_of_work_bits > 34 || c->degree_bits + cfg->rate_bits < cfg->cap_height || !zk_fri_reduction_ok(*cfg, c->degree_bits))
         return ZK_ERR_INVALID_ARG;
     const zk_air *g = c->gates;
-    if ((g->n_instrs && !g->instrs) || (g->n_constants && !g->constants) || g->n_regs == 0 || g->n_regs > 24 || g->n_instrs > (1u << 20)) return ZK_ERR_INVALID_ARG;
+    if ((g->n_instrs && !g->instrs) || (g->n_constants && !g->constants) || g->n_regs == 0 || g->n_regs > 32 || g->n_instrs > (1u << 20)) return ZK_ERR_INVALID_ARG;
     for (u32 p = 0; p < g->n_instrs; p++) {
         const zk_instr &in = g->instrs[p];
-        if (in.op > ZK_OP_EMIT) return ZK_ERR_INVALID_ARG;
+        if (in.op > ZK_OP_EMIT && in.op != ZK_OP_EMIT_SLOT) return ZK_ERR_INVALID_ARG;
+        if (in.op == ZK_OP_EMIT_SLOT && in.dst >= 4096) return ZK_ERR_INVALID_ARG;
         const u32 ops[2] = {in.a, in.b};
         for (int s = 0; s < (in.op <= ZK_OP_MUL ? 2 : 1); s++) {
             const u32 k = ops[s] >> 24, i = ops[s] & 0xFFFFFFu;
@@ -59,6 +69,7 @@ static int32_t plonk_circuit_check(const zk_stark_config *cfg, const zk_plonk_ci
         }
         if (in.op <= ZK_OP_MUL && ((in.dst >> 24) || (in.dst & 0xFFFFFFu) >= g->n_regs)) return ZK_ERR_INVALID_ARG;
     }
+    if (plonk_gate_terms(g) > 4096) return ZK_ERR_INVALID_ARG;
     return ZK_OK;
 }
 
@@ -148,6 +159,36 @@ __global__ __launch_bounds__(256) void plonk_perm_rows_kernel(PermParams p) {
         }
     }
 }
+// the same for any number of chunks (more than PLK_MAX_CHUNKS: routed-wire counts beyond 16 x quotient_degree_factor): prefix numerators
+// go to q, the chunk denominators to a scratch column block `den` [chunk][row], both re-read on the way down
+__global__ __launch_bounds__(256) void plonk_perm_rows_wide_kernel(PermParams p, u64 *den) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= p.n) return;
+    const u64 x = gl_mul(p.xA[r & 2047], p.xB[r >> 11]);
+    for (u32 ci = 0; ci < p.nch; ci++) {
+        const u64 beta = p.bg[ci], gamma = p.bg[p.nch + ci];
+        u64 pn = 1, dall = 1;
+        for (u32 c = 0; c < p.nchunks; c++) {
+            u64 num = 1, d = 1;
+            for (u32 t = 0; t < p.qdf; t++) {
+                const u32 j = c * p.qdf + t;
+                const u64 w = p.wires[(size_t)j * p.n + r];
+                num = gl_mul(num, gl_add(gl_add(w, gl_mul(beta, gl_mul(p.kis[j], x))), gamma));
+                d = gl_mul(d, gl_add(gl_add(w, gl_mul(beta, p.sigmas[(size_t)j * p.n + r])), gamma));
+            }
+            pn = gl_mul(pn, num); dall = gl_mul(dall, d);
+            p.q[((size_t)ci * p.nchunks + c) * p.n + r] = pn;
+            den[(size_t)c * p.n + r] = d;
+        }
+        if (dall == 0) { atomicCAS((unsigned long long *)p.err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_ZERO_INVERSE); }
+        u64 dinv = plk_inv(dall);
+        for (u32 c = p.nchunks; c-- > 0;) {
+            const size_t o = ((size_t)ci * p.nchunks + c) * p.n + r;
+            p.q[o] = gl_mul(p.q[o], dinv);
+            dinv = gl_mul(dinv, den[(size_t)c * p.n + r]);
+        }
+    }
+}
 // Z(w^r) = prod_{s < r} rowprod(s): exclusive prefix product over the rows, one workgroup per challenge
 __global__ __launch_bounds__(1024) void plonk_prefix_product_kernel(const u64 *q, size_t n, u32 nchunks, u64 *z_out /* [challenge][row] */) {
     __shared__ u64 sh[1024];
@@ -183,15 +224,24 @@ struct PlkQuotParams {
     const u64 *w_lde, *z_lde, *cs_lde;     // column-major over L, leaf order
     const u64 *l0;                         // L_0 on the coset, leaf order
     const u64 *xA, *xB;                    // x_i = g w_L^i
-    const u64 *kis, *bg, *alphas;
+    const u64 *kis, *bg;
+    const u64 *apow;                       // [challenge][term]: alpha_j^t for every term t of the vanishing polynomial
     const zk_instr *instrs; const u64 *gconst;
     const u64 *pih;                        // public_inputs_hash (4 words): the PUBLIC operand of the gate program (PublicInputGate)
     u64 zh_inv[8];
-    size_t L; u32 lgL, W, NC, R, NZ, qdf, nchunks, nch, n_instrs, n_regs;
+    size_t L; u32 lgL, W, NC, R, NZ, qdf, nchunks, nch, n_instrs, n_regs, NT;
     u64 *out;                              // [challenge][leaf position]
 };
+// alpha_j^t for t < NT (reduce_with_powers): thread = (challenge, t)
+__global__ void plonk_alpha_pows_kernel(const u64 *alphas, u32 nch, u32 NT, u64 *out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nch * NT) return;
+    out[i] = gl_pow(alphas[i / NT], (u64)(i % NT));
+}
 // eval_vanishing_poly_base_batch at every point of the coset: terms [L_0 (Z_i - 1)] [partial-product checks] [gate constraints],
-// reduce_with_powers with a running power of alpha_j, times 1 / Z_H.  One thread = one coset point; gate registers live in LDS.
+// reduce_with_powers = sum_t term_t alpha_j^t, times 1 / Z_H.  Gate constraints of the same term index add up (every gate is evaluated at
+// every point behind its selector filter), so the sum over terms is taken in whatever order the program emits them: the powers come
+// from a table.  One thread = one coset point; gate registers live in LDS.
 __global__ __launch_bounds__(256) void plonk_quotient_kernel(PlkQuotParams p) {
     extern __shared__ u64 regs[];           // [reg][thread]
     const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -200,16 +250,15 @@ __global__ __launch_bounds__(256) void plonk_quotient_kernel(PlkQuotParams p) {
     const u32 i = bitrev_u32((u32)s, p.lgL);
     const size_t sn = bitrev_u32((u32)((i + p.qdf) & (p.L - 1)), p.lgL);
     const u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);
-    u64 acc[4] = {0, 0, 0, 0}, apow[4] = {1, 1, 1, 1}, al[4];
+    u64 acc[4] = {0, 0, 0, 0};
+    auto emit = [&](u32 term_index, u64 term) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) al[j] = (u32)j < p.nch ? p.alphas[j] : 0;
-    auto emit = [&](u64 term) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) if ((u32)j < p.nch) { acc[j] = gl_add(acc[j], gl_mul(term, apow[j])); apow[j] = gl_mul(apow[j], al[j]); }
+        for (int j = 0; j < 4; j++) if ((u32)j < p.nch) acc[j] = gl_add(acc[j], gl_mul(term, p.apow[(size_t)j * p.NT + term_index]));
     };
     const u32 npp = p.nchunks - 1;
     const u64 l0 = p.l0[s];
-    for (u32 ci = 0; ci < p.nch; ci++) emit(gl_mul(l0, gl_sub(p.z_lde[(size_t)ci * p.L + s], 1)));
+    u32 ti = 0;
+    for (u32 ci = 0; ci < p.nch; ci++) emit(ti++, gl_mul(l0, gl_sub(p.z_lde[(size_t)ci * p.L + s], 1)));
     for (u32 ci = 0; ci < p.nch; ci++) {
         const u64 beta = p.bg[ci], gamma = p.bg[p.nch + ci];
         for (u32 c = 0; c < p.nchunks; c++) {
@@ -222,7 +271,7 @@ __global__ __launch_bounds__(256) void plonk_quotient_kernel(PlkQuotParams p) {
             }
             const u64 prev = c == 0 ? p.z_lde[(size_t)ci * p.L + s] : p.z_lde[((size_t)p.nch + (size_t)ci * npp + c - 1) * p.L + s];
             const u64 next = c == p.nchunks - 1 ? p.z_lde[(size_t)ci * p.L + sn] : p.z_lde[((size_t)p.nch + (size_t)ci * npp + c) * p.L + s];
-            emit(gl_sub(gl_mul(prev, num), gl_mul(next, den)));
+            emit(ti++, gl_sub(gl_mul(prev, num), gl_mul(next, den)));
         }
     }
     auto fetch = [&](u32 o) -> u64 {
@@ -238,7 +287,7 @@ __global__ __launch_bounds__(256) void plonk_quotient_kernel(PlkQuotParams p) {
         if (in.op <= ZK_OP_MUL) {
             const u64 b = fetch(in.b);
             regs[(in.dst & 0xFFFFFFu) * 256 + t] = in.op == ZK_OP_ADD ? gl_add(a, b) : in.op == ZK_OP_SUB ? gl_sub(a, b) : gl_mul(a, b);
-        } else emit(a);
+        } else emit(ti + in.dst, a);          // the device copy of the program carries explicit term indices (zk_plonk_setup)
     }
     u64 zi = p.zh_inv[0];                 // select over constant indices: see quotient_block (prover_quotient.hip)
     {
@@ -272,8 +321,7 @@ extern "C" int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const
     zk_plonk_state *st = new zk_plonk_state();
     st->ctx = ctx; st->c = *c; st->cfg = *cfg; st->c.gates = nullptr; st->c.constants = nullptr; st->c.sigmas = nullptr;
     st->n_instrs = c->gates->n_instrs; st->n_regs = c->gates->n_regs; st->n_gconst = c->gates->n_constants;
-    st->n_gate_terms = 0;
-    for (u32 p = 0; p < c->gates->n_instrs; p++) if (c->gates->instrs[p].op == ZK_OP_EMIT) st->n_gate_terms++;
+    st->n_gate_terms = plonk_gate_terms(c->gates);
     ZkOwned own(ctx);
     u64 *d_cols = (u64 *)own.get((size_t)(NC + R) * n * sizeof(u64));
     st->d_instrs = (zk_instr *)ctx->alloc((size_t)(st->n_instrs ? st->n_instrs : 1) * sizeof(zk_instr));
@@ -284,7 +332,13 @@ extern "C" int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const
     if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_cols, c->constants, (size_t)NC * n * sizeof(u64));
     if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_cols + (size_t)NC * n, c->sigmas, (size_t)R * n * sizeof(u64));
     if (rc == ZK_OK) ZK_LAUNCH(ctx, "plonk_canon", plonk_canon_kernel, g1((size_t)(NC + R) * n), dim3(256), 0, d_cols, (size_t)(NC + R) * n);
-    if (rc == ZK_OK && st->n_instrs) rc = zk_dev_upload(ctx, st->d_instrs, c->gates->instrs, (size_t)st->n_instrs * sizeof(zk_instr));
+    if (rc == ZK_OK && st->n_instrs) {
+        // device copy of the gate program: every emit carries its term index (ZK_OP_EMIT = the running count of EMITs)
+        std::vector<zk_instr> prog(c->gates->instrs, c->gates->instrs + st->n_instrs);
+        u32 seq = 0;
+        for (auto &in : prog) if (in.op == ZK_OP_EMIT) { in.op = ZK_OP_EMIT_SLOT; in.dst = seq++; }
+        rc = zk_dev_upload(ctx, st->d_instrs, prog.data(), prog.size() * sizeof(zk_instr));
+    }
     if (rc == ZK_OK && st->n_gconst) {
         std::vector<u64> gc(c->gates->constants, c->gates->constants + st->n_gconst);
         for (auto &v : gc) v = gl_canon(v);
@@ -297,13 +351,22 @@ extern "C" int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const
     }
     if (rc == ZK_OK) rc = zk_batch_commit_dev(ctx, d_cols, c->degree_bits, NC + R, cfg->rate_bits, cfg->cap_height, 1, &st->cs);
     if (rc == ZK_OK) {
-        // circuit digest = hash_no_pad(constants_sigmas_cap | 0^4 (digest of the empty domain separator) | degree_bits)
-        u64 *d_in = (u64 *)own.get((size_t)(capw + 5) * sizeof(u64));
-        if (!d_in) rc = ZK_ERR_OOM;
+        // CircuitBuilder::build: circuit digest = hash_no_pad(constants_sigmas_cap | hash_pad(domain_separator) | degree_bits);
+        // hash_pad(x) = hash_no_pad(x | 1 | 0.. | 1), padded to a multiple of the rate: [1,0,0,0,0,0,0,1] for the empty separator
+        u32 nd = c->n_domain_separator, np = nd + 1;
+        while ((np + 1) % 8) np++;
+        np++;
+        u64 *d_in = (u64 *)own.get((size_t)(capw + 5) * sizeof(u64)), *d_pad = (u64 *)own.get((size_t)np * sizeof(u64));
+        if (!d_in || !d_pad) rc = ZK_ERR_OOM;
         else {
-            u64 tail[5] = {0, 0, 0, 0, c->degree_bits};
+            std::vector<u64> pad(np, 0);
+            for (u32 i = 0; i < nd; i++) pad[i] = gl_canon(c->domain_separator[i]);
+            pad[nd] = 1; pad[np - 1] = 1;
+            u64 deg = c->degree_bits;
             ZK_LAUNCH(ctx, "plonk_copy", plonk_copy_kernel, g1(capw), dim3(256), 0, st->cs->cap(), d_in, capw);
-            rc = zk_dev_upload(ctx, d_in + capw, tail, sizeof tail);
+            rc = zk_dev_upload(ctx, d_pad, pad.data(), pad.size() * sizeof(u64));
+            if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_in + capw + 4, &deg, sizeof deg);
+            if (rc == ZK_OK) ZK_LAUNCH(ctx, "plonk_hash_no_pad", plonk_hash_no_pad_kernel, dim3(1), dim3(1), 0, (const u64 *)d_pad, np, d_in + capw);
             if (rc == ZK_OK) ZK_LAUNCH(ctx, "plonk_hash_no_pad", plonk_hash_no_pad_kernel, dim3(1), dim3(1), 0, (const u64 *)d_in, capw + 5, st->d_digest);
             if (rc == ZK_OK) rc = zk_dev_download(ctx, st->digest, st->d_digest, 4 * sizeof(u64));
         }
@@ -327,7 +390,9 @@ extern "C" int32_t zk_plonk_circuit_digest(zk_plonk_state *st, uint64_t digest_o
 
 extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_plonk_state *st, const uint64_t *wires, uint32_t wires_on_device,
                                   const uint64_t *public_inputs, uint32_t n_pub, uint64_t *proof_out, size_t cap_words, size_t *len_words) {
-    if (!ctx || !cfgp || !st || !wires || !proof_out || (n_pub && !public_inputs) || st->ctx != ctx) return ZK_ERR_INVALID_ARG;
+    // the prover data of a circuit is read-only after zk_plonk_setup (which ends with a host wait): any context of the same device may prove with it,
+    // as every worker of the reference shares one P_STATE (/root/reference/common/src/prover_state/mod.rs:24-31)
+    if (!ctx || !cfgp || !st || !wires || !proof_out || (n_pub && !public_inputs) || st->ctx->device != ctx->device) return ZK_ERR_INVALID_ARG;
     if (memcmp(cfgp, &st->cfg, sizeof(zk_stark_config)) != 0) return ctx->fail(ZK_ERR_INVALID_ARG, "prove_plonk: config differs from the one of zk_plonk_setup");
     const zk_stark_config &cfg = st->cfg;
     const zk_plonk_circuit &c = st->c;
@@ -405,7 +470,13 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
         rc = zk_ntt_dit(ctx, st->cs->coeffs + (size_t)NC * n, n, d_sig, n, k, R, 0, nullptr, nullptr, 0, nullptr, 0);
         pp.sigmas = d_sig;
         if (rc == ZK_OK) {
-            ZK_LAUNCH(ctx, "plonk_perm_rows", plonk_perm_rows_kernel, g1(n), dim3(256), 0, pp);
+            if (nchunks <= PLK_MAX_CHUNKS) ZK_LAUNCH(ctx, "plonk_perm_rows", plonk_perm_rows_kernel, g1(n), dim3(256), 0, pp);
+            else {
+                u64 *d_den = (u64 *)A_((size_t)nchunks * n * sizeof(u64));
+                if (!d_den) rc = ctx->fail(ZK_ERR_OOM, "prove_plonk: out of device memory");
+                else ZK_LAUNCH(ctx, "plonk_perm_rows_wide", plonk_perm_rows_wide_kernel, g1(n), dim3(256), 0, pp, d_den);
+            }
+            if (rc) { ctx->release(d_sig); ctx->release(d_q); ctx->release(d_zpp); return rc; }
             ZK_LAUNCH(ctx, "plonk_prefix_product", plonk_prefix_product_kernel, dim3(nch), dim3(1024), 0, (const u64 *)d_q, n, nchunks, d_zpp);
             if (npp) ZK_LAUNCH(ctx, "plonk_partial_products", plonk_partial_products_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, (const u64 *)d_q, n, nchunks, nch, d_zpp);
             rc = zk_batch_commit_dev(ctx, d_zpp, k, NZ, cfg.rate_bits, cfg.cap_height, 1, &g.zb);
@@ -430,7 +501,11 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
             PlkQuotParams qp = {};
             qp.w_lde = g.wb->lde; qp.z_lde = g.zb->lde; qp.cs_lde = st->cs->lde; qp.l0 = lag;
             TwoLevel xs = zk_scale_table(ctx, gl_root(lgL), GL_GEN, lgL);
-            qp.xA = xs.A; qp.xB = xs.B; qp.kis = st->d_kis; qp.bg = d_bg; qp.alphas = d_alphas; qp.instrs = st->d_instrs; qp.gconst = st->d_gconst;
+            const u32 NT = nch + nch * nchunks + st->n_gate_terms;
+            u64 *d_apow = (u64 *)A_((size_t)nch * NT * sizeof(u64));
+            if (!d_apow) { ctx->release(d_qv); return ctx->fail(ZK_ERR_OOM, "prove_plonk: out of device memory"); }
+            ZK_LAUNCH(ctx, "plonk_alpha_pows", plonk_alpha_pows_kernel, g1((size_t)nch * NT), dim3(256), 0, (const u64 *)d_alphas, nch, NT, d_apow);
+            qp.xA = xs.A; qp.xB = xs.B; qp.kis = st->d_kis; qp.bg = d_bg; qp.apow = d_apow; qp.NT = NT; qp.instrs = st->d_instrs; qp.gconst = st->d_gconst;
             const u64 gn = gl_pow(GL_GEN, n), wr = gl_root(cfg.rate_bits);
             for (u32 i = 0; i < qdf; i++) qp.zh_inv[i] = gl_inv(gl_sub(gl_mul(gn, gl_pow(wr, i)), 1));
             qp.L = L; qp.lgL = lgL; qp.W = W; qp.NC = NC; qp.R = R; qp.NZ = NZ; qp.qdf = qdf; qp.nchunks = nchunks; qp.nch = nch;
@@ -469,9 +544,7 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
         a.n = q;
         zk_transcript_run(ctx, ch, a);
     }
-    // ---- prove_openings: the instance's points are needed on the host (16 bytes, the only mid-proof download)
-    u64 hz[4];
-    if ((rc = zk_dev_download(ctx, hz, d_zeta, sizeof hz)) != ZK_OK) return rc;
+    // ---- prove_openings over [constants_sigmas, wires, zs_partial_products, quotient]; zeta and g*zeta stay in HBM (d_zeta)
     {
         const zk_batch *oracles[4] = {st->cs, g.wb, g.zb, g.qb};
         std::vector<zk_fri_poly> p0, p1;
@@ -481,8 +554,8 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
         for (u32 i = 0; i < Q; i++) p0.push_back({3, i});
         for (u32 i = 0; i < nch; i++) p1.push_back({2, i});
         FriBatchDesc bt[2];
-        bt[0].point[0] = hz[0]; bt[0].point[1] = hz[1]; bt[0].n_polys = (u32)p0.size(); bt[0].polys = p0.data();
-        bt[1].point[0] = hz[2]; bt[1].point[1] = hz[3]; bt[1].n_polys = (u32)p1.size(); bt[1].polys = p1.data();
+        bt[0].point[0] = bt[0].point[1] = 0; bt[0].n_polys = (u32)p0.size(); bt[0].polys = p0.data(); bt[0].d_point = d_zeta;
+        bt[1].point[0] = bt[1].point[1] = 0; bt[1].n_polys = (u32)p1.size(); bt[1].polys = p1.data(); bt[1].d_point = d_zeta + 2;
         rc = zk_fri_prove_instance_dev(ctx, cfg, ch, oracles, 4, bt, 2, d_proof + y.o_fri, y.fri);
         if (rc) return rc;
     }

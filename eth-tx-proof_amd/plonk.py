@@ -24,21 +24,23 @@ GEN = 14293326489335486720
 class PlonkCircuit(C.Structure):
     """zk_plonk_circuit (include/zkgl.h)"""
     _fields_ = [("degree_bits", u32), ("num_wires", u32), ("num_routed_wires", u32), ("num_constants", u32),
-                ("quotient_degree_factor", u32), ("reserved", u32), ("gates", C.c_void_p), ("constants", C.c_void_p),
-                ("sigmas", C.c_void_p)]
+                ("quotient_degree_factor", u32), ("n_domain_separator", u32), ("gates", C.c_void_p), ("constants", C.c_void_p),
+                ("sigmas", C.c_void_p), ("domain_separator", C.c_void_p)]
 
 
 class Circuit:
     """Owns the arrays behind a zk_plonk_circuit; `.ref` is a pointer to the struct."""
 
-    def __init__(self, degree_bits, num_wires, num_routed, constants, sigmas, gates, qdf=8):
+    def __init__(self, degree_bits, num_wires, num_routed, constants, sigmas, gates, qdf=8, domain_separator=None):
         self.degree_bits, self.num_wires, self.num_routed, self.qdf = degree_bits, num_wires, num_routed, qdf
         self.constants = np.ascontiguousarray(constants, dtype=np.uint64)
         self.sigmas = np.ascontiguousarray(sigmas, dtype=np.uint64)
         self.num_constants = self.constants.shape[0]
         self.gates = gates
-        self.c = PlonkCircuit(degree_bits, num_wires, num_routed, self.num_constants, qdf, 0, C.cast(gates.ref, C.c_void_p),
-                              self.constants.ctypes.data, self.sigmas.ctypes.data)
+        self.domain_separator = np.ascontiguousarray([] if domain_separator is None else domain_separator, dtype=np.uint64)
+        self.c = PlonkCircuit(degree_bits, num_wires, num_routed, self.num_constants, qdf, self.domain_separator.size,
+                              C.cast(gates.ref, C.c_void_p), self.constants.ctypes.data, self.sigmas.ctypes.data,
+                              self.domain_separator.ctypes.data if self.domain_separator.size else None)
         self.ref = C.pointer(self.c)
 
 
@@ -182,3 +184,102 @@ class SyntheticRecursion:
         prev_d = self.digest(ctx, prev) if prev is not None else np.zeros(4, dtype=np.uint64)
         pubs = np.concatenate([np.array([height], dtype=np.uint64), self.digest(ctx, agg.proof), prev_d])
         return self.state(ctx, "block"), self.witness(ctx, "block", pubs), pubs
+
+
+# ------------------------------------------------------------------------------------------------ circuits of the recursion shape
+# share of the rows per gate in a recursive-verifier-like circuit: Merkle paths (PoseidonGate) dominate, then the arithmetic of
+# the FRI checks and of the vanishing-polynomial evaluation; the rest of the rows up to the power of two are NoopGates
+RECURSION_MIX = (("PoseidonGate", 0.60), ("ArithmeticGate", 0.14), ("ArithmeticExtensionGate", 0.08), ("ReducingGate", 0.05),
+                 ("BaseSumGate", 0.05), ("ConstantGate", 0.02))
+POSEIDON_CHAIN = 4          # PoseidonGate rows come in chains (a Merkle path: digest out -> input of the next row, a copy constraint)
+_circuit_cache = {}
+
+
+def recursion_circuit(degree_bits=12, seed=1, num_wires=135, num_routed=80, domain_separator=None):
+    """(Circuit, wires): a circuit with the gate set, selector polynomials, gate mix and wire routing shape of plonky2's recursion
+    circuits (gates.py) and a satisfying witness -- the STAND-IN for the shrink / root / aggregation / block circuits of
+    AllRecursiveCircuits (/root/reference/common/src/prover_state/circuit.rs:200-206), whose gadgets are not in the reference tree.
+    Row 0 is the PublicInputGate (wires 0..3 = public_inputs_hash: `bind_public_inputs`).  It verifies nothing in-circuit."""
+    from . import gates as GT
+    from . import glnp as G
+    key = (degree_bits, seed, num_wires, num_routed, None if domain_separator is None else tuple(int(x) for x in domain_separator))
+    if key in _circuit_cache:
+        return _circuit_cache[key]
+    assert num_wires >= 135 and num_routed >= 80 and num_routed % 8 == 0 and degree_bits >= 3
+    n = 1 << degree_bits
+    rng = np.random.default_rng([seed, degree_bits])
+    prog, groups = GT.gate_program(num_wires)
+    NS = len(groups)
+    # ---- rows per gate
+    counts, left = {}, n - 1
+    for name, share in RECURSION_MIX:
+        c = min(left, int(share * n))
+        if name == "PoseidonGate":
+            c -= c % POSEIDON_CHAIN
+        counts[name] = c
+        left -= c
+    gate_of_row = np.full(n, GT.GATE_INDEX["NoopGate"], dtype=np.int64)
+    gate_of_row[0] = GT.GATE_INDEX["PublicInputGate"]
+    rows, at = {}, 1
+    for name, _ in RECURSION_MIX:
+        rows[name] = np.arange(at, at + counts[name])
+        gate_of_row[rows[name]] = GT.GATE_INDEX[name]
+        at += counts[name]
+    # ---- constants: selector polynomials, then the gates' local constants
+    consts = np.zeros((NS + GT.NUM_GATE_CONSTANTS, n), dtype=np.uint64)
+    for gi, (lo, hi) in enumerate(groups):
+        inside = (gate_of_row >= lo) & (gate_of_row < hi)
+        consts[gi] = np.where(inside, gate_of_row, GT.UNUSED_SELECTOR if NS > 1 else 0).astype(np.uint64)
+    consts[NS:] = G.rand(rng, (GT.NUM_GATE_CONSTANTS, n))
+    k0, k1 = consts[NS], consts[NS + 1]
+    # ---- witness
+    wires = G.rand(rng, (num_wires, n))
+    wires[:4, 0] = 0                                            # PublicInputGate cells: bind_public_inputs
+    pairs = []                                                  # copy constraints: (col_a, rows_a, col_b, rows_b), cell by cell
+    pr = rows["PoseidonGate"]
+    if pr.size:
+        chains = pr.reshape(POSEIDON_CHAIN, -1)                 # chains[t] = the t-th row of every chain
+        prev_out = None
+        for t in range(POSEIDON_CHAIN):
+            m = chains.shape[1]
+            inp = G.rand(rng, (12, m))
+            if prev_out is not None:
+                inp[0:4] = prev_out
+            blk = GT.poseidon_rows(inp, rng.integers(0, 2, size=m, dtype=np.uint64))
+            wires[:135, chains[t]] = blk
+            if prev_out is not None:
+                for i in range(4):
+                    pairs.append((GT.PG_IN + i, chains[t], GT.PG_OUT + i, chains[t - 1]))
+            prev_out = blk[GT.PG_OUT:GT.PG_OUT + 4]
+    r_ = rows["ArithmeticGate"]
+    if r_.size:
+        wires[:135, r_] = GT.arithmetic_rows(rng, r_.size, k0[r_], k1[r_])
+        for j in range(1, GT.ARITH_OPS):
+            pairs.append((4 * j, r_, 4 * j - 1, r_))
+    r_ = rows["ArithmeticExtensionGate"]
+    if r_.size:
+        wires[:135, r_] = GT.arithmetic_ext_rows(rng, r_.size, k0[r_], k1[r_])
+    r_ = rows["ReducingGate"]
+    if r_.size:
+        wires[:135, r_] = GT.reducing_rows(rng, r_.size)
+    r_ = rows["BaseSumGate"]
+    if r_.size:
+        wires[:135, r_] = GT.base_sum_rows(rng, r_.size)
+    r_ = rows["ConstantGate"]
+    if r_.size:
+        wires[:135, r_] = GT.constant_rows(rng, r_.size, k0[r_], k1[r_])
+    # ---- routed-wire permutation: sigma_j(w^r) = k_j' w^r' of the cell that (j, r) maps to; every class above is a 2-cycle
+    wpow = G.powers(_root(degree_bits), n)
+    ident = np.stack([G.mul(G.scalar(_pow(GEN, j), wpow), wpow) for j in range(num_routed)])
+    sig = ident.copy()
+    for ca, ra, cb, rb in pairs:
+        assert ca < num_routed and cb < num_routed
+        sig[ca, ra] = ident[cb, rb]
+        sig[cb, rb] = ident[ca, ra]
+    circ = Circuit(degree_bits, num_wires, num_routed, consts, sig, prog, domain_separator=domain_separator)
+    circ.pi_wires = [0, 1, 2, 3]
+    circ.gate_rows = {k: v for k, v in rows.items()}
+    circ.gate_of_row = gate_of_row
+    out = (circ, np.ascontiguousarray(wires, dtype=np.uint64))
+    _circuit_cache[key] = out
+    return out

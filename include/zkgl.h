@@ -163,7 +163,9 @@ enum {
 enum {
     ZK_OP_ADD = 0, ZK_OP_SUB = 1, ZK_OP_MUL = 2,
     /* ConstraintConsumer::{constraint, constraint_transition, constraint_first_row, constraint_last_row}(a) */
-    ZK_OP_EMIT = 3, ZK_OP_EMIT_TRANSITION = 4, ZK_OP_EMIT_FIRST = 5, ZK_OP_EMIT_LAST = 6
+    ZK_OP_EMIT = 3, ZK_OP_EMIT_TRANSITION = 4, ZK_OP_EMIT_FIRST = 5, ZK_OP_EMIT_LAST = 6,
+    /* gate programs of zk_plonk_circuit only: gate constraint term `dst` += a (see zk_plonk_circuit below) */
+    ZK_OP_EMIT_SLOT = 7
 };
 #define ZK_OPND(kind, idx) (((uint32_t)(kind) << 24) | (uint32_t)(idx))
 typedef struct { uint32_t op, dst, a, b; } zk_instr;
@@ -365,8 +367,13 @@ int32_t zk_fri_commit_free(zk_fri_commit *s);
  *   quotient chunks commit -> zeta -> OpeningSet -> PolynomialBatch::prove_openings over the four oracles
  *   (constants_sigmas, wires, zs_partial_products, quotient; batches at zeta and at g*zeta for the Zs).
  * Gate program: zk_air with n_trace_cols = num_wires + num_constants (LOCAL index i < num_wires = wire i, else constant column
- * i - num_wires), ops ADD / SUB / MUL / EMIT only, no NEXT / CHALLENGE operands, n_helpers = 0; PUBLIC index i < 4 = word i of
- * public_inputs_hash = hash_no_pad(public_inputs) -- what upstream's PublicInputGate constrains its wires against.
+ * i - num_wires), ops ADD / SUB / MUL / EMIT / EMIT_SLOT only, no NEXT / CHALLENGE operands, n_helpers = 0; PUBLIC index i < 4 = word i
+ * of public_inputs_hash = hash_no_pad(public_inputs) -- what upstream's PublicInputGate constrains its wires against.
+ * Constraint terms: upstream evaluates EVERY gate of the circuit at every point, each multiplied by its selector filter, and ADDS
+ * the gates' constraints position by position (plonk::vanishing_poly::evaluate_gate_constraints_base_batch: constraints_batch[j] +=
+ * gate_constraints[j]), so the vanishing polynomial has max-over-gates(num_constraints) gate terms.  ZK_OP_EMIT_SLOT (dst = j) adds
+ * its operand to gate term j; ZK_OP_EMIT adds to term (number of ZK_OP_EMIT instructions before it).  Number of gate terms =
+ * 1 + the highest term index written (at most 4096).
  *
  * Proof words: "ZKGLPLK1", degree_bits, num_wires, num_routed, num_constants, wires_cap, zs_partial_products_cap, quotient_cap,
  *   openings: constants[NC x2] sigmas[R x2] wires[W x2] zs[nch x2] zs_next[nch x2] partial_products[nch*npp x2]
@@ -374,18 +381,19 @@ int32_t zk_fri_commit_free(zk_fri_commit *s);
 typedef struct {
     uint32_t degree_bits;             /* n = 2^degree_bits rows */
     uint32_t num_wires;               /* 135 */
-    uint32_t num_routed_wires;        /* 80; a multiple of quotient_degree_factor, at most 16 chunks of it (128 at factor 8):
-                                       * wider permutations are refused with ZK_ERR_INVALID_ARG (upstream has no such limit) */
+    uint32_t num_routed_wires;        /* 80; a multiple of quotient_degree_factor (any number of chunks) */
     uint32_t num_constants;           /* constant + selector columns */
     uint32_t quotient_degree_factor;  /* 8: chunk size of the partial products, number of quotient chunks per challenge */
-    uint32_t reserved;
+    uint32_t n_domain_separator;      /* words of CircuitBuilder::set_domain_separator (0: none, as in every circuit of the reference) */
     const zk_air *gates;              /* the gate-constraint program */
     const uint64_t *constants;        /* num_constants x n, column-major: values on the subgroup H */
     const uint64_t *sigmas;           /* num_routed_wires x n: sigma_j(w^r) = k_j' * w^r' for the cell (j', r') that (j, r) maps to, k_j = g^j */
+    const uint64_t *domain_separator; /* n_domain_separator words (may be NULL when 0) */
 } zk_plonk_circuit;
 typedef struct zk_plonk_state zk_plonk_state;   /* prover data of one circuit: constants_sigmas commitment, digest; device resident */
 /* CircuitBuilder::build's prover-side part: commit constants | sigmas (rate_bits, cap_height of cfg), derive the circuit digest
- * = hash_no_pad(cap | 0^4 | degree_bits).  cfg: zk_stark_config with the recursion parameters (rate_bits 3, 28 query rounds ..). */
+ * = hash_no_pad(constants_sigmas_cap | hash_pad(domain_separator) | degree_bits); hash_pad = pad10*1 to a multiple of the rate,
+ * so the empty separator hashes [1,0,0,0,0,0,0,1].  cfg: zk_stark_config with the recursion parameters (rate_bits 3, 28 query rounds ..). */
 int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const zk_plonk_circuit *circuit, zk_plonk_state **out);
 int32_t zk_plonk_state_free(zk_plonk_state *st);
 int32_t zk_plonk_circuit_digest(zk_plonk_state *st, uint64_t digest_out[4]);

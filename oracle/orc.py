@@ -12,7 +12,7 @@ u64p = C.POINTER(C.c_uint64)
 
 def build(force=False):
     so = os.path.join(_here, "liboracle.so")
-    srcs = [os.path.join(_here, f) for f in ("prims.c", "stark.c", "verify.c", "gl.h", "oracle.h", "poseidon_constants.h")]
+    srcs = [os.path.join(_here, f) for f in ("prims.c", "stark.c", "verify.c", "plonk.c", "gl.h", "oracle.h", "poseidon_constants.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _here, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -66,6 +66,14 @@ def hash_rows(rows):
     rows = u64(rows)
     out = np.empty((rows.shape[0], 4), dtype=np.uint64)
     lib().orc_hash_rows(_p(rows), C.c_size_t(rows.shape[0]), C.c_uint32(rows.shape[1]), _p(out))
+    return out
+
+
+def hash_no_pad(xs):
+    """PoseidonHash::hash_no_pad of one vector (always the sponge: no hash_or_noop copy branch)"""
+    xs = u64(xs)
+    out = np.empty(4, dtype=np.uint64)
+    lib().orc_hash_no_pad(_p(xs), C.c_size_t(xs.size), _p(out))
     return out
 
 

@@ -37,8 +37,19 @@ static int fri_arities_p_checked(const zk_stark_config *cfg, uint32_t degree_bit
 static void fri_arities_p(const zk_stark_config *cfg, uint32_t degree_bits, uint32_t *out, uint32_t *n_out) { (void)fri_arities_p_checked(cfg, degree_bits, out, n_out); }
 
 /* gate program over the base field: LOCAL i < W is wire i, otherwise constant column i - W.  Emitted terms are appended to out. */
+/* number of gate constraint terms: ZK_OP_EMIT writes term (number of EMITs before it), ZK_OP_EMIT_SLOT term `dst`; terms ADD UP
+ * (upstream: evaluate_gate_constraints_base_batch sums the filtered constraints of all gates position by position) */
+static uint32_t n_gate_terms(const zk_air *g) {
+    uint32_t c = 0, hi = 0;
+    for (uint32_t p = 0; p < g->n_instrs; p++) {
+        if (g->instrs[p].op == ZK_OP_EMIT) c++;
+        else if (g->instrs[p].op == ZK_OP_EMIT_SLOT && g->instrs[p].dst + 1 > hi) hi = g->instrs[p].dst + 1;
+    }
+    return c > hi ? c : hi;
+}
 static uint32_t gates_base(const zk_air *g, const uint64_t *wires, const uint64_t *consts, uint32_t W, const uint64_t *pih, uint64_t *regs, uint64_t *out) {
-    uint32_t n_out = 0;
+    uint32_t n_out = 0, NG = n_gate_terms(g);
+    for (uint32_t j = 0; j < NG; j++) out[j] = 0;
     for (uint32_t p = 0; p < g->n_instrs; p++) {
         const zk_instr *in = &g->instrs[p];
         uint64_t v[2]; uint32_t ops[2] = {in->a, in->b};
@@ -48,12 +59,14 @@ static uint32_t gates_base(const zk_air *g, const uint64_t *wires, const uint64_
             if (in->op > ZK_OP_MUL) break;
         }
         if (in->op <= ZK_OP_MUL) regs[in->dst & 0xFFFFFF] = in->op == ZK_OP_ADD ? gl_add(v[0], v[1]) : in->op == ZK_OP_SUB ? gl_sub(v[0], v[1]) : gl_mul(v[0], v[1]);
-        else out[n_out++] = v[0];
+        else if (in->op == ZK_OP_EMIT) { out[n_out] = gl_add(out[n_out], v[0]); n_out++; }
+        else out[in->dst] = gl_add(out[in->dst], v[0]);
     }
-    return n_out;
+    return NG;
 }
 static uint32_t gates_ext(const zk_air *g, const gl2 *wires, const gl2 *consts, uint32_t W, const uint64_t *pih, gl2 *regs, gl2 *out) {
-    uint32_t n_out = 0;
+    uint32_t n_out = 0, NG = n_gate_terms(g);
+    for (uint32_t j = 0; j < NG; j++) out[j] = gl2_from(0);
     for (uint32_t p = 0; p < g->n_instrs; p++) {
         const zk_instr *in = &g->instrs[p];
         gl2 v[2]; uint32_t ops[2] = {in->a, in->b};
@@ -63,21 +76,23 @@ static uint32_t gates_ext(const zk_air *g, const gl2 *wires, const gl2 *consts, 
             if (in->op > ZK_OP_MUL) break;
         }
         if (in->op <= ZK_OP_MUL) regs[in->dst & 0xFFFFFF] = in->op == ZK_OP_ADD ? gl2_add(v[0], v[1]) : in->op == ZK_OP_SUB ? gl2_sub(v[0], v[1]) : gl2_mul(v[0], v[1]);
-        else out[n_out++] = v[0];
+        else if (in->op == ZK_OP_EMIT) { out[n_out] = gl2_add(out[n_out], v[0]); n_out++; }
+        else out[in->dst] = gl2_add(out[in->dst], v[0]);
     }
-    return n_out;
+    return NG;
 }
-static uint32_t n_gate_terms(const zk_air *g) { uint32_t c = 0; for (uint32_t p = 0; p < g->n_instrs; p++) if (g->instrs[p].op == ZK_OP_EMIT) c++; return c; }
 
 static int circuit_ok(const zk_stark_config *cfg, const zk_plonk_circuit *c) {
     if (!cfg || !c || !c->gates || !c->constants || !c->sigmas) return 0;
     if (c->degree_bits < 2 || c->degree_bits > 24 || c->num_wires == 0 || c->num_routed_wires == 0 || c->num_routed_wires > c->num_wires) return 0;
+    if (c->n_domain_separator > 4096 || (c->n_domain_separator && !c->domain_separator) || n_gate_terms(c->gates) > 4096) return 0;
     if (c->quotient_degree_factor != (1u << cfg->rate_bits) || c->num_routed_wires % c->quotient_degree_factor) return 0;
     if (cfg->num_challenges == 0 || cfg->num_challenges > 4) return 0;
     { uint32_t ar_[64], nl_; if (c->degree_bits + cfg->rate_bits < cfg->cap_height || !fri_arities_p_checked(cfg, c->degree_bits, ar_, &nl_)) return 0; }
     for (uint32_t p = 0; p < c->gates->n_instrs; p++) {
         const zk_instr *in = &c->gates->instrs[p];
-        if (in->op > ZK_OP_EMIT) return 0;
+        if (in->op > ZK_OP_EMIT && in->op != ZK_OP_EMIT_SLOT) return 0;
+        if (in->op == ZK_OP_EMIT_SLOT && in->dst >= 4096) return 0;
         uint32_t ops[2] = {in->a, in->b};
         for (int s = 0; s < (in->op <= ZK_OP_MUL ? 2 : 1); s++) {
             uint32_t k = ops[s] >> 24, i = ops[s] & 0xFFFFFF;
@@ -115,10 +130,21 @@ orc_plonk_state *orc_plonk_setup(const zk_stark_config *cfg, const zk_plonk_circ
     st->c = *c;
     st->cs = orc_batch_from_values(cols, c->degree_bits, NC + R, cfg->rate_bits, cfg->cap_height);
     free(cols);
-    /* circuit_digest = hash_no_pad(constants_sigmas_cap | domain separator digest (empty: zeros) | degree_bits) */
+    /* CircuitBuilder::build: circuit_digest = hash_no_pad(constants_sigmas_cap | hash_pad(domain_separator) | degree_bits), with
+     * hash_pad(x) = hash_no_pad(x | 1 | 0.. | 1) padded to a multiple of the rate (8): the empty separator hashes [1,0,0,0,0,0,0,1] */
     uint32_t capw = 4u << cfg->cap_height;
     uint64_t *in = (uint64_t *)calloc(capw + 5, sizeof(uint64_t));
     memcpy(in, orc_batch_cap(st->cs), capw * sizeof(uint64_t));
+    {
+        uint32_t nd = c->n_domain_separator, np = nd + 1;
+        while ((np + 1) % 8) np++;
+        np++;
+        uint64_t *pad = (uint64_t *)calloc(np, sizeof(uint64_t));
+        for (uint32_t i = 0; i < nd; i++) pad[i] = gl_canon(c->domain_separator[i]);
+        pad[nd] = 1; pad[np - 1] = 1;
+        orc_hash_no_pad(pad, np, in + capw);
+        free(pad);
+    }
     in[capw + 4] = c->degree_bits;
     orc_hash_no_pad(in, capw + 5, st->digest);
     free(in);

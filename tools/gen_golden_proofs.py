@@ -39,6 +39,18 @@ def digests():
     assert rc == 0 and orc.verify_plonk(st, pubs, p) == 0
     out["plonk_proof"] = {"degree_bits": 7, "seed": 5, "public_inputs": [1, 2, 3], "words": int(p.size), "sha256": hashlib.sha256(p.tobytes()).hexdigest(),
                           "circuit_digest": ["%016x" % int(x) for x in st.digest()]}
+    # circuits of the recursion shape (gates.py: PoseidonGate + arithmetic / reducing / base-sum gates behind selector filters)
+    rec = []
+    for k, seed in ((8, 11), (13, 12)):
+        circ, wires = plonk.recursion_circuit(degree_bits=k, seed=seed)
+        st = orc.PlonkState(rcfg, circ)
+        pubs = np.array([k, seed, 7], dtype=np.uint64)
+        w = plonk.bind_public_inputs(circ, wires, orc.hash_no_pad(pubs))
+        rc, p = orc.prove_plonk(st, w, pubs)
+        assert rc == 0 and orc.verify_plonk(st, pubs, p) == 0
+        rec.append({"degree_bits": k, "seed": seed, "public_inputs": [k, seed, 7], "words": int(p.size), "sha256": hashlib.sha256(p.tobytes()).hexdigest(),
+                    "circuit_digest": ["%016x" % int(x) for x in st.digest()]})
+    out["recursion_plonk_proofs"] = rec
     return out
 
 
