@@ -11,7 +11,8 @@ configuration (one 2^23-row unit) the same way.
 
 Multi-GPU: units are independent (reference: IndexedStream.map(&TxProof), leader/src/prover.rs:26-27), so ranks shard
 units with no data-path collective ("scaling": "weak"); the only exchange is the hand-off of finished proofs to rank 0
-(torch.distributed gather over RCCL), inside the timed region.  `--gpus N` with no WORLD_SIZE in the environment starts
+(host buffers over a gloo group, each proof sent from a background thread while the next unit is proved: sharding.Handoff), inside the
+timed region; RCCL carries the barrier and the max-over-ranks timing.  `--gpus N` with no WORLD_SIZE in the environment starts
 the N ranks itself (child processes, before anything in this process touches the GPU); under torch.distributed.run the
 environment's WORLD_SIZE must equal --gpus.
 
@@ -63,9 +64,25 @@ def fan_out(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
+    # rank 0's output is drained by a thread while ALL children are watched: a rank that dies takes the others down with it (they
+    # would otherwise wait in a collective for ever) and the failure is the exit code
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        sys.stderr.write("bench.py: rank %d exited with code %d; the other ranks were stopped\n" % (failed, procs[failed].returncode))
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+    rd.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
@@ -92,8 +109,11 @@ def algorithmic_bytes_per_launch(kernel, log_n, rate_bits):
     return None
 
 
-def cpu_baseline(log_n_target, n_cols, n_helpers, budget_s=20.0):
-    """The oracle (CPU restatement, kind "port") timed on this host's cores on a bounded sample of the same workload."""
+def cpu_baseline(log_n_target, n_cols, n_helpers, budget_s=45.0, check_proof=None):
+    """The oracle (CPU restatement, kind "port") timed on this host's cores on the same workload.  The thread count is chosen AT a
+    size near the sample's (2^17 rows: OpenMP team start-up no longer decides), and the sample is the target size itself whenever one
+    proof fits the budget -- then nothing is scaled.  check_proof: (proof words, pub) of a unit proved in the timed region: the
+    oracle's verifier must accept it (returned as "timed_proof_verified")."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     import eth_tx_proof_amd as E
@@ -102,36 +122,50 @@ def cpu_baseline(log_n_target, n_cols, n_helpers, budget_s=20.0):
     prog = air.cpu_like_air(n_cols, n_helpers)
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # pick the thread count that is fastest on a small case (a cgroup may grant fewer CPUs than the affinity mask shows)
-    cal_tr, cal_pub = orc.synth_trace(n_cols, 9, 1)
+    verified = None
+    if check_proof is not None:
+        orc.lib().orc_set_threads(min(avail, 16))
+        verified = orc.verify(cfg, [(prog, log_n_target, None, check_proof[1])], check_proof[0]) == 0
+    log_c = min(log_n_target, 17)
+    cal_tr, cal_pub = orc.synth_trace(n_cols, log_c, 1)
     best = None
-    for th in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 32), min(avail, 16), min(avail, 8)}, reverse=True):
+    for th in sorted({avail, max(1, avail // 2), max(1, avail // 4), min(avail, 64)}, reverse=True):
         orc.lib().orc_set_threads(th)
         t0 = time.time()
-        orc.prove(cfg, [(prog, 9, cal_tr, cal_pub)])
+        orc.prove(cfg, [(prog, log_c, cal_tr, cal_pub)])
         dt = time.time() - t0
         if best is None or dt < best[1]:
             best = (th, dt)
+    del cal_tr
     cores = best[0]
     orc.lib().orc_set_threads(cores)
-    log_s, t_s = 11, None
-    while True:
-        tr, pub = orc.synth_trace(n_cols, log_s, 1)
-        t0 = time.time()
-        rc, proof = orc.prove(cfg, [(prog, log_s, tr, pub)])
-        dt = time.time() - t0
-        assert rc == 0
-        t_s = dt
-        if dt * 2.2 > budget_s or log_s >= log_n_target or log_s >= 18:
-            break
-        log_s += 1
-    # work of a unit proof grows like N log N (NTTs) on top of N (hashing): scale the sample by N log N, the larger of the two
-    scale = float(log_n_target << log_n_target) / float(log_s << log_s)
-    return {"value": 1.0 / (t_s * scale), "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": "oracle/ C restatement (OpenMP, %d threads), one unit proof at 2^%d rows x %d cols (+%d aux) in %.2f s, "
-                      "scaled by N log N (x%.2f) to 2^%d rows; a naive scalar port, NOT the reference's AVX2/rayon prover: "
-                      "the GPU/CPU ratio is not a speed-up over the reference"
-                      % (cores, log_s, n_cols, 2 * (n_helpers + 1) if n_helpers else 0, t_s, scale, log_n_target)}
+    nlogn = lambda lg: float(lg << lg)
+    log_s = log_n_target
+    while log_s > log_c and best[1] * nlogn(log_s) / nlogn(log_c) > budget_s:      # the largest size whose estimate fits the budget
+        log_s -= 1
+    tr, pub = orc.synth_trace(n_cols, log_s, 1)
+    t0 = time.time()
+    rc, proof = orc.prove(cfg, [(prog, log_s, tr, pub)])
+    t_s = time.time() - t0
+    assert rc == 0
+    scale = nlogn(log_n_target) / nlogn(log_s)
+    how = "nothing scaled" if log_s == log_n_target else "scaled by N log N (x%.2f) to 2^%d rows" % (scale, log_n_target)
+    return {"value": 1.0 / (t_s * scale), "unit": "proofs/s", "cores": cores, "hardware_threads": avail, "kind": "port",
+            "sample_log_n": log_s, "sample_seconds": round(t_s, 2), "timed_proof_verified": verified,
+            "sample": "oracle/ C restatement (OpenMP, %d of %d hardware threads, thread count chosen at 2^%d rows), one unit proof at 2^%d rows "
+                      "x %d cols (+%d aux) in %.2f s, %s; a naive scalar port, NOT the reference's AVX2/rayon prover: the GPU/CPU ratio "
+                      "is not a speed-up over the reference" % (cores, avail, log_c, log_s, n_cols, 2 * (n_helpers + 1) if n_helpers else 0, t_s, how)}
+
+
+def golden_digest(log_n, n_cols, n_helpers, seed):
+    """sha256 of the ORACLE's proof of this bench unit, when committed (tests/golden/proof_digests_big.json: 2^20 / 2^22 / 2^23)"""
+    f = os.path.join(ROOT, "tests", "golden", "proof_digests_big.json")
+    if not os.path.exists(f):
+        return None
+    for e in json.load(open(f)).get("unit_proofs", []):
+        if (e["log_n"], e["n_cols"], e["n_helpers"], e["seed"]) == (log_n, n_cols, n_helpers, seed):
+            return e["sha256"]
+    return None
 
 
 def int_alu_peak():
@@ -211,31 +245,38 @@ def main():
 
     errors = []
 
-    def work(s, k=1, keep=None):
-        """Worker s proves k units back to back on its own context / stream (a paladin worker pulls its next unit as soon as one is done)."""
+    def work(s, k=1, ho=None):
+        """Worker s proves k units back to back on its own context / stream (a paladin worker pulls its next unit as soon as one is done);
+        with several ranks every finished proof goes straight to the background hand-off (sharding.Handoff), never to a list."""
         try:
             for j in range(k):
                 zl.prove_tables(ctxs[s], cfg, [(prog, args.log_n, traces[s].data_ptr(), pubs[s])], out=outs[s])
-                if keep is not None:
-                    keep[j * args.inflight + s] = outs[s].copy()
+                if ho is not None:
+                    ho.put(rank + world * (j * args.inflight + s), outs[s])        # unit m of this rank = rank + world * m
         except Exception as e:   # surfaced after join
             errors.append(e)
+
+    handoff = {"exposed_s": 0.0, "bytes": 0}
 
     def run_steps(k):
         """k steps = k x `inflight` unit proofs on this rank.  The steps are pipelined: each of the `inflight` workers proves its k units
         back to back, so the GPU does not drain at every step boundary -- the barrier + synchronize brackets are around the whole
-        timed region, as the contract says, not around each step."""
-        keep = {} if world > 1 else None
-        th = [threading.Thread(target=work, args=(s, k, keep)) for s in range(args.inflight)]
+        timed region, as the contract says, not around each step.  N > 1: the finished proofs travel to rank 0 (where
+        leader.ProverInput.prove folds them) WHILE the next units are proved; what is left at the end -- the last proofs in flight and one
+        status broadcast -- is `handoff.exposed_s`."""
+        ho = sharding.Handoff(k * args.inflight * world, group=host_pg) if world > 1 else None
+        th = [threading.Thread(target=work, args=(s, k, ho)) for s in range(args.inflight)]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        if ho is not None:
+            got = ho.finish(ok=not errors)
+            handoff["exposed_s"], handoff["bytes"] = ho.exposed_s, ho.bytes
+            if rank == 0 and any(g is None for g in got):
+                raise RuntimeError("hand-off: a proof is missing on rank 0")
         if errors:
             raise errors[0]
-        if world > 1:   # hand the finished proofs to rank 0 (leader.ProverInput.prove folds them there); unit m of this rank = rank + world * m
-            mine = {rank + world * m: p for m, p in keep.items()}
-            sharding.gather_proofs(mine, k * args.inflight * world, group=host_pg)
 
     def fence():
         if world > 1:
@@ -265,6 +306,7 @@ def main():
     dbg("timed steps done")
     units = args.steps * args.inflight * world
     value = units / dt
+    handoff_timed = dict(handoff)
 
     # ---- the same steps with the hipEvent profiler on every stream: kernel table and roofline
     solo, rep, dt_prof, phases = {}, {}, None, {}
@@ -356,6 +398,10 @@ def main():
             "value_profiled": (units / dt_prof) if dt_prof else None,
             "value_pcie_inclusive": pcie,
         }
+        if world > 1:       # the only exchange of the job: finished proofs to rank 0, overlapped with proving (sharding.Handoff)
+            line["handoff"] = {"exposed_ms": handoff_timed["exposed_s"] * 1e3, "share_of_timed_region": handoff_timed["exposed_s"] / dt,
+                               "MB_into_rank0": handoff_timed["bytes"] / 1e6, "backend": "gloo host group, per-proof send from a background thread",
+                               "note": "exposed = what rank 0 still waited for after its own last unit (last proofs in flight + one status broadcast)"}
         if rep:
             proofs0 = args.steps * args.inflight     # unit proofs this rank produced in the profiled region
             tot_ms = sum(ms for _, ms in rep.values()) or 1.0
@@ -420,8 +466,22 @@ def main():
             # (93-column trace commit and 40-column auxiliary commit); this is the same mixed average from the hipEvent timings
             ll = [(l, ms) for k, (l, ms) in rep.items() if leaf_label_cols(k) is not None]
             line["roofline"]["avg_launch_ms_all_leaf_hash_shapes"] = sum(ms for _, ms in ll) / max(1, sum(l for l, _ in ll))
+        # ---- a proof of the timed region, checked after the clock has stopped: its sha256 against the oracle's committed digest of the
+        # same unit (bit-exact parity without oracle time), and the oracle's verifier in the cpu_baseline leg
+        import hashlib
+        seed0 = 0x5EED0000 + 1000 * (rank * args.inflight)
+        gold = golden_digest(args.log_n, C, args.helpers, seed0)
+        got = hashlib.sha256(outs[0].tobytes()).hexdigest()
+        line["timed_proof_check"] = {"unit": "worker 0, seed %#x" % seed0, "sha256": got, "oracle_sha256": gold,
+                                     "identical_to_oracle": (got == gold) if gold else None}
+        if gold and got != gold:
+            print(json.dumps(line))
+            sys.exit("bench.py: the proof of the timed region differs from the oracle's (sha256 %s != %s)" % (got, gold))
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.log_n, C, args.helpers)
+            line["cpu_baseline"] = cpu_baseline(args.log_n, C, args.helpers, check_proof=(outs[0], pubs[0]))
+            if line["cpu_baseline"]["timed_proof_verified"] is False:
+                print(json.dumps(line))
+                sys.exit("bench.py: the oracle's verifier rejects a proof of the timed region")
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

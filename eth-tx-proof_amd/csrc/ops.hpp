@@ -1,6 +1,7 @@
 // C++ host-side mirror of the reference's operator surface over the C ABI (include/zkgl.h).
 //   /root/reference/ops/src/lib.rs:16-18   fn p_state() -> &'static ProverState   (P_STATE.get().expect(..))
 //   /root/reference/ops/src/lib.rs:22-62   TxProof: Operation { execute(GenerationInputs) -> Result<AggregatableProof> }
+//                                          = prove_root: zk_prove_tables, per table initial wrapper + shrinking wrappers, root proof
 //   /root/reference/ops/src/lib.rs:64-82   AggProof: Monoid   { combine, empty }            (zk_prove_plonk)
 //   /root/reference/ops/src/lib.rs:84-101  BlockProof: Operation                              (zk_prove_plonk)
 //   /root/reference/leader/src/prover.rs:14-43  ProverInput::prove = map(&TxProof).fold(&AggProof) -> BlockProof
@@ -45,6 +46,11 @@ struct PlonkJob {
     std::vector<uint64_t> public_inputs;
 };
 struct RecursionCircuits {             // supplied by the integrator; called on the worker thread with its context
+    // by_table[table].by_stark_size[log_n]: number of circuits in the chain (1 initial wrapper + shrinking wrappers); 0 = "Missing
+    // preprocessed circuits for table with size" (FatalError).  Step 0 gets the table's StarkProof words, step i > 0 the proof of step i-1.
+    std::function<uint32_t(uint32_t table, const zk_table &)> shrink_chain_len;
+    std::function<PlonkJob(zk_ctx *, uint32_t table, const zk_table &, uint32_t step, const std::vector<uint64_t> &inner)> shrink_step;
+    std::function<PlonkJob(zk_ctx *, const std::vector<std::vector<uint64_t>> &shrunk, const std::vector<zk_table> &)> root;
     std::function<PlonkJob(zk_ctx *, const AggregatableProof &, const AggregatableProof &)> aggregation;
     std::function<PlonkJob(zk_ctx *, const std::vector<uint64_t> *prev, const AggregatableProof &)> block;
 };
@@ -53,16 +59,18 @@ struct ProverState {                   // common::prover_state::ProverState: bui
     int device = 0;
     zk_stark_config config;
     RecursionCircuits recursion;
+    bool stark_only = false;           // TxProof stops after the STARK proofs (BASELINE's headline unit), on explicit request only
 };
 inline ProverState *&p_state_slot() { static ProverState *s = nullptr; return s; }
 inline std::mutex &p_state_mutex() { static std::mutex m; return m; }
 // common/src/prover_state/mod.rs:59-95; a second call leaves the first state (worker/src/main.rs:25-27 only warns)
-inline bool set_prover_state_from_config(int device, RecursionCircuits recursion = {}) {
+inline bool set_prover_state_from_config(int device, RecursionCircuits recursion = {}, bool stark_only = false) {
     std::lock_guard<std::mutex> g(p_state_mutex());
     if (p_state_slot()) return false;
     auto *s = new ProverState();
     s->device = device;
     s->recursion = std::move(recursion);
+    s->stark_only = stark_only;
     zk_stark_config_standard_fast(&s->config);     // circuit.rs:200-206
     p_state_slot() = s;
     return true;
@@ -81,33 +89,60 @@ inline zk_ctx *thread_ctx() {
     return ctx;
 }
 
-struct TxProof {
-    double last_seconds = 0.0;
-    AggregatableProof execute(GenerationInputs input) {
-        const ProverState &st = p_state();
-        zk_ctx *ctx = thread_ctx();
-        auto t0 = std::chrono::steady_clock::now();
-        AggregatableProof out;
-        out.proof.resize(zk_proof_size_words(&st.config, (uint32_t)input.tables.size(), input.tables.data()));
-        size_t len = 0;
-        int32_t rc = zk_prove_tables(ctx, &st.config, (uint32_t)input.tables.size(), input.tables.data(), out.proof.data(),
-                                     out.proof.size(), &len);
-        if (rc != ZK_OK) throw FatalError(std::string("generate_txn_proof: ") + zk_last_error(ctx));   // lib.rs:52
-        out.proof.resize(len);
-        last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();    // lib.rs:53-58
-        return out;
-    }
-};
 inline std::vector<uint64_t> prove_plonk_job(const char *what, const PlonkJob &job) {
     zk_ctx *ctx = thread_ctx();
     std::vector<uint64_t> proof(zk_plonk_proof_size_words(job.cfg, job.circuit));
     size_t len = 0;
     int32_t rc = zk_prove_plonk(ctx, job.cfg, job.state, job.wires, job.wires_on_device, job.public_inputs.data(),
                                 (uint32_t)job.public_inputs.size(), proof.data(), proof.size(), &len);
-    if (rc != ZK_OK) throw FatalError(std::string(what) + ": " + zk_last_error(ctx));               // lib.rs:72,96
+    if (rc != ZK_OK) throw FatalError(std::string(what) + ": " + zk_last_error(ctx));               // lib.rs:52,72,96
     proof.resize(len);
     return proof;
 }
+// evm_arithmetization::prover::prove: the STARK proofs of all tables on one challenger
+inline std::vector<uint64_t> prove(const GenerationInputs &input) {
+    const ProverState &st = p_state();
+    zk_ctx *ctx = thread_ctx();
+    std::vector<uint64_t> out(zk_proof_size_words(&st.config, (uint32_t)input.tables.size(), input.tables.data()));
+    size_t len = 0;
+    int32_t rc = zk_prove_tables(ctx, &st.config, (uint32_t)input.tables.size(), input.tables.data(), out.data(), out.size(), &len);
+    if (rc != ZK_OK) throw FatalError(std::string("generate_txn_proof: ") + zk_last_error(ctx));   // lib.rs:52
+    out.resize(len);
+    return out;
+}
+// AllRecursiveCircuits::prove_root: prove(), then per table the shrink chain, then the root circuit
+inline std::vector<uint64_t> prove_root(const GenerationInputs &input) {
+    const ProverState &st = p_state();
+    const RecursionCircuits &rc = st.recursion;
+    if (!rc.shrink_chain_len || !rc.shrink_step || !rc.root)
+        throw FatalError("generate_txn_proof: no recursion circuits in the prover state (SURVEY.md 8f-2, A10)");
+    zk_ctx *ctx = thread_ctx();
+    const std::vector<uint64_t> all_proof = prove(input);
+    std::vector<std::vector<uint64_t>> shrunk;
+    size_t at = 2;                                         // "ZKGLPRF1", n_tables, then the tables' StarkProof words back to back
+    for (uint32_t t = 0; t < input.tables.size(); t++) {
+        const size_t n = zk_proof_size_words(&st.config, 1, &input.tables[t]) - 2;
+        std::vector<uint64_t> proof(all_proof.begin() + at, all_proof.begin() + at + n);
+        at += n;
+        const uint32_t steps = rc.shrink_chain_len(t, input.tables[t]);
+        if (!steps) throw FatalError("Missing preprocessed circuits for table " + std::to_string(t) + " with size " + std::to_string(input.tables[t].log_n) + ".");
+        for (uint32_t i = 0; i < steps; i++) proof = prove_plonk_job("shrink", rc.shrink_step(ctx, t, input.tables[t], i, proof));
+        shrunk.push_back(std::move(proof));
+    }
+    return prove_plonk_job("root", rc.root(ctx, shrunk, input.tables));
+}
+
+struct TxProof {
+    double last_seconds = 0.0;
+    AggregatableProof execute(GenerationInputs input) {
+        const ProverState &st = p_state();
+        auto t0 = std::chrono::steady_clock::now();
+        AggregatableProof out;
+        out.proof = st.stark_only ? prove(input) : prove_root(input);                                // lib.rs:52
+        last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();    // lib.rs:53-58
+        return out;
+    }
+};
 struct AggProof {
     AggregatableProof combine(const AggregatableProof &a, const AggregatableProof &b) {
         const ProverState &st = p_state();

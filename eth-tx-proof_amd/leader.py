@@ -30,8 +30,9 @@ class Runtime:
         self.num_workers, self.max_requeue = max(1, num_workers), max_requeue
         self.requeued = []          # (unit index, error text) of every re-queued unit, for the log
 
-    def map(self, op, inputs, indices=None):
-        """Runs op.execute over `inputs` on the worker threads; results in input order.  Raises the first FatalError."""
+    def map(self, op, inputs, indices=None, on_result=None):
+        """Runs op.execute over `inputs` on the worker threads; results in input order.  Raises the first FatalError.
+        on_result(index, result): called from the worker thread as soon as a unit is done (the proof hand-off starts there)."""
         idx = list(range(len(inputs))) if indices is None else list(indices)
         q = queue.Queue()
         for k, i in enumerate(idx):
@@ -46,6 +47,8 @@ class Runtime:
                     return
                 try:
                     res[k] = op.execute(inputs[k])
+                    if on_result is not None:
+                        on_result(i, res[k])
                 except ops.FatalError as e:
                     code = getattr(e.__cause__, "code", None)
                     if code in DEVICE_ERRORS and tries < self.max_requeue:
@@ -90,15 +93,28 @@ class ProverInput:
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         mine = sharding.shard_units(n, world, rank)
-        local = runtime.map(ops.TxProof(), [self.proof_gen_ir[i] for i in mine], indices=mine)      # .map(&TxProof)
         if world > 1:
-            words = sharding.gather_proofs({i: p.proof for i, p in zip(mine, local)}, n, device=device, group=group)
+            # every finished proof goes to rank 0 while the next unit is being proved; a rank whose map stage fails tells the others
+            # (sharding.Handoff.finish), so nobody is left waiting in a collective.  group: a HOST (gloo) group -- finished proofs
+            # are host buffers; None = sharding.cached_host_group(), whatever the default group's backend is
+            ho = sharding.Handoff(n, group=group)
+            failed = None
+            try:
+                runtime.map(ops.TxProof(), [self.proof_gen_ir[i] for i in mine], indices=mine,                 # .map(&TxProof)
+                            on_result=lambda i, p: ho.put(i, p.proof))
+            except ops.FatalError as e:
+                failed = e
+            try:
+                words = ho.finish(ok=failed is None)
+            except sharding.HandoffError as e:
+                raise (failed or ops.FatalError(str(e))) from e
+            self.handoff = {"exposed_s": ho.exposed_s, "bytes": ho.bytes}
             if rank != 0:
                 return None
-            # public values travel with the inputs (every rank holds proof_gen_ir), the proof words with the gather
+            # public values travel with the inputs (every rank holds proof_gen_ir), the proof words with the hand-off
             txs = [ops.AggregatableProof("Txn", w, [t.public_inputs for t in self.proof_gen_ir[i].tables]) for i, w in enumerate(words)]
         else:
-            txs = local
+            txs = runtime.map(ops.TxProof(), [self.proof_gen_ir[i] for i in mine], indices=mine)              # .map(&TxProof)
         agg = Runtime.fold(ops.AggProof(), txs)                                                    # .fold(&AggProof)
         if agg.kind != "Agg":
             raise RuntimeError("AggProof is is not GeneratedAggProof")                              # prover.rs:41 (bail!)

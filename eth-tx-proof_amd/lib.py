@@ -66,6 +66,7 @@ class Context:
 
     def __init__(self, device=0, stream=None):
         self.h = C.c_void_p()
+        self.device = device
         rc = lib().zk_ctx_create(C.c_int32(device), C.c_void_p(stream), C.byref(self.h))
         if rc:
             self.h = None
@@ -481,8 +482,10 @@ def plonk_proof_size_words(cfg, circuit):
     return f(C.byref(cfg), circuit.ref)
 
 
-def prove_plonk(state, wires, public_inputs):
-    """zk_prove_plonk: wires = (num_wires, n) uint64 host array or an int device pointer (canonical values)."""
+def prove_plonk(state, wires, public_inputs, ctx=None):
+    """zk_prove_plonk: wires = (num_wires, n) uint64 host array or an int device pointer (canonical values).  ctx: the context
+    (stream) to prove on -- any context of the device the circuit's prover data lives on; default: the one it was built with."""
+    ctx = ctx or state.ctx
     pub = _u64(public_inputs)
     n = plonk_proof_size_words(state.cfg, state.circuit)
     out = np.empty(n, dtype=np.uint64)
@@ -492,9 +495,9 @@ def prove_plonk(state, wires, public_inputs):
     else:
         keep = wires if (isinstance(wires, np.ndarray) and wires.dtype == np.uint64 and wires.flags.c_contiguous) else _u64(wires)
         wp, on_dev = keep.ctypes.data_as(C.c_void_p), 0
-    rc = lib().zk_prove_plonk(state.ctx.h, C.byref(state.cfg), state.h, wp, C.c_uint32(on_dev), _p(pub), C.c_uint32(pub.size), _p(out),
+    rc = lib().zk_prove_plonk(ctx.h, C.byref(state.cfg), state.h, wp, C.c_uint32(on_dev), _p(pub), C.c_uint32(pub.size), _p(out),
                               C.c_size_t(n), C.byref(ln))
-    state.ctx._chk(rc, "zk_prove_plonk")
+    ctx._chk(rc, "zk_prove_plonk")
     return out[:ln.value]
 
 

@@ -2,7 +2,8 @@
 
   reference                                   here
   P_STATE: OnceLock<ProverState>              P_STATE / set_prover_state_from_config   (common/src/prover_state/mod.rs:31,59-95)
-  TxProof: Operation  (lib.rs:22-62)          TxProof.execute(input) -> AggregatableProof.Txn
+  TxProof: Operation  (lib.rs:22-62)          TxProof.execute(input) -> AggregatableProof.Txn   = prove_root: prove (the STARK proofs of all
+                                              tables, zk_prove_tables) -> per table initial wrapper + shrinking wrappers -> root proof
   AggProof: Monoid    (lib.rs:64-82)          AggProof.combine / .empty  (zk_prove_plonk over the circuits in p_state().recursion)
   BlockProof: Operation (lib.rs:84-101)       BlockProof.execute          (same)
 
@@ -61,8 +62,23 @@ class GeneratedBlockProof:
 
 class RecursionCircuits:
     """The circuits of the Plonk half as data + their witness generators (upstream: AllRecursiveCircuits inside ProverState,
-    /root/reference/common/src/prover_state/mod.rs:31-57).  Each method returns (lib.PlonkState on `ctx`, wires, public_inputs):
-    the circuit's prover data, a (num_wires, n) witness (host array or device pointer) and the public inputs of THIS proof."""
+    /root/reference/common/src/prover_state/mod.rs:31-57: by_table[t].by_stark_size[degree_bits] = {initial_wrapper,
+    shrinking_wrappers}, root, aggregation, block).  Each proving method returns (lib.PlonkState, wires, public_inputs): the circuit's
+    prover data (on the caller's device), a (num_wires, n) witness (host array or device pointer) and the public inputs of THIS proof."""
+
+    def shrink_chain(self, table, air, log_n):
+        """the circuits for this table at this STARK size, initial wrapper first; raises KeyError when none were built for the size
+        (upstream: "Missing preprocessed circuits for {table} table with size {degree_bits}")"""
+        raise NotImplementedError
+
+    def initial_wrapper(self, ctx, table, air, log_n, stark_proof_words):
+        raise NotImplementedError
+
+    def shrinking_wrapper(self, ctx, table, air, log_n, step, inner_proof):
+        raise NotImplementedError
+
+    def root(self, ctx, shrunk_proofs, stark_sizes):
+        raise NotImplementedError
 
     def aggregation(self, ctx, lhs: "AggregatableProof", rhs: "AggregatableProof"):
         raise NotImplementedError
@@ -74,11 +90,22 @@ class RecursionCircuits:
 class ProverState:
     """Per-process immutable prover state: StarkConfig + one zk_ctx per worker thread (+ the recursion circuits, if supplied)."""
 
-    def __init__(self, device=0, config=None, recursion: Optional[RecursionCircuits] = None):
+    def __init__(self, device=0, config=None, recursion: Optional[RecursionCircuits] = None, stark_only=False):
+        """stark_only: TxProof.execute stops after the STARK proofs (BASELINE's headline unit) instead of failing for want of
+        recursion circuits; never set together with `recursion`."""
         self.device = device
         self.config = config or standard_fast_config()
         self.recursion = recursion
+        self.stark_only = bool(stark_only) and recursion is None
         self._tls = threading.local()
+        self._state_ctx, self._state_lock = None, threading.Lock()
+
+    def state_ctx(self):
+        """The context that owns process-wide prover data (circuit commitments): never dropped on a worker's device error."""
+        with self._state_lock:
+            if self._state_ctx is None:
+                self._state_ctx = zl.Context(self.device)
+            return self._state_ctx
 
     def ctx(self):
         c = getattr(self._tls, "ctx", None)
@@ -108,13 +135,13 @@ P_STATE: Optional[ProverState] = None
 _lock = threading.Lock()
 
 
-def set_prover_state_from_config(device=0, config=None, recursion=None):
+def set_prover_state_from_config(device=0, config=None, recursion=None, stark_only=False):
     """Initialises the global prover state once; a second call leaves the first state in place and returns it
     (the reference only warns on double initialisation, worker/src/main.rs:25-27)."""
     global P_STATE
     with _lock:
         if P_STATE is None:
-            P_STATE = ProverState(device, config, recursion)
+            P_STATE = ProverState(device, config, recursion, stark_only)
         return P_STATE
 
 
@@ -122,6 +149,57 @@ def p_state():
     if P_STATE is None:
         raise RuntimeError("Prover state is not initialized")     # lib.rs:17 `.expect(..)`
     return P_STATE
+
+
+def split_all_proof(cfg, tables, all_proof):
+    """The per-table StarkProof words of an AllProof (zkgl.h proof layout: "ZKGLPRF1", n_tables, then the tables back to back)."""
+    out, at = [], 2
+    for t in tables:
+        n = zl.proof_size_words(cfg, [(t.air, t.log_n, t.trace, t.public_inputs)]) - 2
+        out.append(all_proof[at:at + n])
+        at += n
+    if at != len(all_proof):
+        raise FatalError("AllProof of %d words does not split into its %d tables" % (len(all_proof), len(tables)))
+    return out
+
+
+def prove(input: "GenerationInputs") -> np.ndarray:
+    """evm_arithmetization::prover::prove: the STARK proofs of all tables of one transaction on one challenger (zk_prove_tables)."""
+    st = p_state()
+    items = [(t.air, t.log_n, t.trace, t.public_inputs) for t in input.tables]
+    return zl.prove_tables(st.ctx(), st.config, items)
+
+
+def prove_root(input: "GenerationInputs", timing: Optional[dict] = None):
+    """AllRecursiveCircuits::prove_root (what generate_txn_proof at /root/reference/ops/src/lib.rs:52 calls): prove(), then for every
+    table  by_table[t].by_stark_size[degree_bits].shrink(stark_proof)  = initial_wrapper.prove, then every shrinking wrapper, then
+    root.circuit.prove over the shrunk proofs.  Returns (root proof words, public values, all_proof words)."""
+    st = p_state()
+    rc = st.recursion
+    if rc is None:
+        raise FatalError("generate_txn_proof: no recursion circuits in the prover state (SURVEY.md 8f-2, A10): pass ProverState(recursion=...)")
+    ctx = st.ctx()
+    t0 = time.time()
+    all_proof = prove(input)
+    t1 = time.time()
+    shrunk = []
+    for ti, (t, words) in enumerate(zip(input.tables, split_all_proof(st.config, input.tables, all_proof))):
+        try:
+            chain = rc.shrink_chain(ti, t.air, t.log_n)
+        except KeyError as e:
+            raise FatalError(str(e.args[0])) from e
+        state, wires, pubs = rc.initial_wrapper(ctx, ti, t.air, t.log_n, words)
+        proof = zl.prove_plonk(state, wires, pubs, ctx=ctx)
+        for step in range(1, len(chain)):
+            state, wires, pubs = rc.shrinking_wrapper(ctx, ti, t.air, t.log_n, step, proof)
+            proof = zl.prove_plonk(state, wires, pubs, ctx=ctx)
+        shrunk.append(proof)
+    t2 = time.time()
+    state, wires, pubs = rc.root(ctx, shrunk, [t.log_n for t in input.tables])
+    root = zl.prove_plonk(state, wires, pubs, ctx=ctx)
+    if timing is not None:
+        timing.update(stark_s=t1 - t0, shrink_s=t2 - t1, root_s=time.time() - t2)
+    return root, [t.public_inputs for t in input.tables], all_proof
 
 
 class TxProof:
@@ -133,12 +211,16 @@ class TxProof:
         st = p_state()
         t0 = time.time()
         try:
-            items = [(t.air, t.log_n, t.trace, t.public_inputs) for t in input.tables]
-            proof = zl.prove_tables(st.ctx(), st.config, items)
+            if st.stark_only:       # the STARK half alone (BASELINE's unit), on explicit request only
+                proof, pv = prove(input), [t.public_inputs for t in input.tables]
+            else:
+                proof, pv, _ = prove_root(input)
+        except FatalError:
+            raise
         except Exception as e:      # generate_txn_proof(..).map_err(FatalError::from)?   lib.rs:52
             raise FatalError(str(e)) from e
         self.last = (ident, time.time() - t0)                                                     # lib.rs:53-58 log line
-        return AggregatableProof("Txn", proof, [t.public_inputs for t in input.tables])
+        return AggregatableProof("Txn", proof, pv)
 
 
 def _prove_recursive(what, build):
@@ -147,8 +229,9 @@ def _prove_recursive(what, build):
         raise FatalError("%s: no recursion circuits in the prover state (SURVEY.md 8f-2, A10): pass ProverState(recursion=...); "
                          "zk_prove_plonk proves circuits given as data" % what)
     try:
-        state, wires, pubs = build(st.recursion, st.ctx())
-        return zl.prove_plonk(state, wires, pubs), np.asarray(pubs, dtype=np.uint64)
+        ctx = st.ctx()
+        state, wires, pubs = build(st.recursion, ctx)
+        return zl.prove_plonk(state, wires, pubs, ctx=ctx), np.asarray(pubs, dtype=np.uint64)
     except FatalError:
         raise
     except Exception as e:          # .map_err(FatalError::from)?   lib.rs:72,96

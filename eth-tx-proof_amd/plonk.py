@@ -145,45 +145,152 @@ def bind_public_inputs(circuit, wires, public_inputs_hash):
 
 
 class SyntheticRecursion:
-    """STAND-IN for the recursion circuits (ops.RecursionCircuits) so that the reference's caller shape
-    map(&TxProof) -> fold(&AggProof) -> BlockProof (/root/reference/leader/src/prover.rs:26-36) can run end to end on the GPU Plonk
-    prover.  NOT recursion: the circuits are `synthetic_circuit`s of the recursion config's shape and do not verify their children;
-    a child is bound to its parent through the parent's public inputs -- the Poseidon digests (hash_no_pad, on the GPU) of the
-    children's proof words -- which the circuits constrain with upstream's PublicInputGate (their witness carries
-    public_inputs_hash in the gate's wires).  The real aggregation / block circuits are data a maintainer supplies the same way."""
+    """STAND-IN for AllRecursiveCircuits (ops.RecursionCircuits; upstream: evm_arithmetization::fixed_recursive_verifier, held by the
+    prover state, /root/reference/common/src/prover_state/mod.rs:31-57) so that the reference's whole flow
 
-    def __init__(self, cfg=None, degree_bits=12, seed=1):
-        from ._abi import standard_recursion_config
+        TxProof = prove_root:  7 STARK proofs -> per table initial_wrapper + shrinking_wrappers (until degree_bits <= 13) -> root
+        map(&TxProof) -> fold(&AggProof) -> BlockProof                                   (/root/reference/leader/src/prover.rs:26-36)
+
+    runs end to end on the GPU Plonk prover.  NOT recursion: every circuit is a `recursion_circuit` -- the gate set, selector
+    polynomials, gate mix and routing of plonky2's recursion circuits (gates.py) at the SIZE the real circuit is estimated to have --
+    and verifies nothing in-circuit.  A child is bound to its parent through the parent's public inputs: the Poseidon Merkle roots
+    (`digest`, on the GPU) of the children's proof words, which the circuit's PublicInputGate constrains (its wires carry
+    public_inputs_hash).  The real circuits are data a maintainer supplies the same way.
+
+    Sizes (degree bits) -- estimates of the real circuits' row counts, NOT taken from the reference (absent):
+      initial wrapper of a table  = a circuit verifying one STARK proof: 84 queries x (leaf hashing ceil(C/8) + ceil(A/8) rows, three
+                                    Merkle paths, the FRI layers' leaves / paths / interpolation, reducing 2C + 2A + Q openings with alpha)
+                                    + hashing the openings + the constraints at zeta           (`initial_wrapper_degree_bits`)
+      shrinking wrapper           = a circuit verifying one recursion-config proof: 2^12 rows (plonky2's own figure for its recursion
+                                    circuit); appended while the previous circuit has more than 2^threshold rows (upstream: 13)
+      root 2^15 (seven 2^12-row verifiers and the public-value plumbing), aggregation 2^14 (two verifiers), block 2^14.
+    size_shift moves every size (tests run the same flow on small circuits: size_shift=-6, threshold=7)."""
+
+    ROOT_BITS, AGG_BITS, BLOCK_BITS, SHRINK_BITS, THRESHOLD_DEGREE_BITS = 15, 14, 14, 12, 13
+
+    def __init__(self, cfg=None, degree_bits=None, seed=1, size_shift=0, threshold=None, degree_bits_ranges=None, stark_cfg=None):
+        """degree_bits: (legacy) fixed size of the aggregation / block circuits.  degree_bits_ranges: per table (lo, hi) half-open
+        ranges of STARK sizes circuits exist for, like the reference's *_CIRCUIT_SIZE settings
+        (/root/reference/common/src/prover_state/circuit.rs:76-100); None = every size."""
+        import threading
+        from ._abi import standard_fast_config, standard_recursion_config
         self.cfg = cfg or standard_recursion_config()
-        self.circuits = {"agg": synthetic_circuit(degree_bits=degree_bits, seed=seed, public_input_gate=True),
-                         "block": synthetic_circuit(degree_bits=degree_bits, seed=seed + 1, public_input_gate=True)}
-        self._states = {}
+        self.stark_cfg = stark_cfg or standard_fast_config()
+        self.seed, self.shift = seed, size_shift
+        self.threshold = (self.THRESHOLD_DEGREE_BITS + size_shift) if threshold is None else threshold
+        self.ranges = degree_bits_ranges
+        self.fixed_bits = degree_bits
+        self._states, self._lock = {}, threading.Lock()
 
-    def state(self, ctx, kind):
-        """The circuit's prover data on this context, built once (upstream: ProverState holds the circuits for the process)."""
+    # ---- sizes
+    def _bits(self, b):
+        return max(3, b + self.shift)
+
+    def initial_wrapper_degree_bits(self, n_cols, n_aux, log_n):
+        c = self.stark_cfg
+        q = c.num_challenges << c.rate_bits
+        lg = log_n + c.rate_bits
+        layers, d = [], log_n
+        while d > c.fri_final_poly_bits and d + c.rate_bits - c.fri_arity_bits >= c.cap_height:
+            d -= c.fri_arity_bits
+            layers.append(d + c.rate_bits)
+        per_query = -(-n_cols // 8) + -(-n_aux // 8) + 3 * (lg - c.cap_height) + sum(4 + (l - c.cap_height) + 2 for l in layers) \
+            + -(-(2 * n_cols + 2 * n_aux + q) // 43)
+        rows = c.num_query_rounds * per_query + (4 * n_cols + 4 * n_aux + 2 * q) // 8 + (n_cols + n_aux) // 2 + 64
+        return self._bits(max(self.SHRINK_BITS, (rows - 1).bit_length()))
+
+    def chain_degree_bits(self, n_cols, n_aux, log_n):
+        """[initial wrapper, shrinking wrappers ..]: RecursiveCircuitsForTableSize::new shrinks until degree_bits <= threshold"""
+        bits = [self.initial_wrapper_degree_bits(n_cols, n_aux, log_n)]
+        while bits[-1] > self.threshold:
+            bits.append(self._bits(self.SHRINK_BITS))
+            if bits[-1] >= bits[-2]:
+                break
+        return bits
+
+    # ---- circuits and their prover data
+    def circuit(self, kind, key=0, degree_bits=None):
+        """(Circuit, wires) of one stand-in circuit; kind in initial / shrink / root / agg / block, key = (table, stark size, step)"""
+        if degree_bits is None:
+            degree_bits = {"root": self._bits(self.ROOT_BITS), "agg": self.fixed_bits or self._bits(self.AGG_BITS),
+                           "block": self.fixed_bits or self._bits(self.BLOCK_BITS)}[kind]
+        import zlib
+        sd = zlib.crc32(repr((kind, key)).encode()) & 0xFFFF
+        return recursion_circuit(degree_bits=degree_bits, seed=self.seed * 65536 + sd)
+
+    @property
+    def circuits(self):
+        return {"agg": self.circuit("agg"), "block": self.circuit("block")}
+
+    def state(self, ctx, kind, key=0, degree_bits=None):
+        """The circuit's prover data, built once per device (upstream: ProverState holds the circuits for the process; every worker
+        proves with the same data).  Built on the prover state's own context when there is one, so that a worker's context can be
+        dropped after a device error without taking the circuits with it."""
         from . import lib as zl
-        key = (id(ctx), kind)
-        if key not in self._states:
-            self._states[key] = (ctx, zl.PlonkState(ctx, self.cfg, self.circuits[kind][0]))
-        return self._states[key][1]
+        k = (ctx.device, kind, key, degree_bits)
+        with self._lock:
+            if k not in self._states:
+                from . import ops
+                owner = ops.P_STATE.state_ctx() if ops.P_STATE is not None and ops.P_STATE.device == ctx.device else ctx
+                self._states[k] = zl.PlonkState(owner, self.cfg, self.circuit(kind, key, degree_bits)[0])
+            return self._states[k]
 
     @staticmethod
     def digest(ctx, words):
-        return ctx.hash_rows(np.ascontiguousarray(words, dtype=np.uint64)[None, :])[0]
+        """The digest that binds a child proof into its parent's public inputs: the Merkle cap of height 0 (the root) over the proof
+        words in leaves of eight, zero-padded to a power of two of leaves -- one zk_merkle_build on the GPU.  (A sponge over the whole
+        proof is a serial chain of words / 8 permutations: seconds for a wide table's StarkProof.)"""
+        w = np.ascontiguousarray(words, dtype=np.uint64).ravel()
+        n_leaves = max(2, 1 << (max(1, -(-w.size // 8)) - 1).bit_length())
+        leaves = np.zeros((n_leaves, 8), dtype=np.uint64)
+        leaves.ravel()[:w.size] = w
+        return ctx.merkle_build(leaves, 0, want_digests=False)[0][0]
 
-    def witness(self, ctx, kind, pubs):
-        """The circuit's witness for these public inputs: the PublicInputGate's wires carry hash_no_pad(public inputs)."""
-        circ, wires = self.circuits[kind]
-        return bind_public_inputs(circ, wires, self.digest(ctx, pubs))
+    @staticmethod
+    def public_inputs_hash(ctx, pubs):
+        """hash_no_pad(public inputs): always the sponge (hash_rows copies rows of <= 4 words: pad to the sponge by hand)"""
+        pubs = np.ascontiguousarray(pubs, dtype=np.uint64)
+        if pubs.size > 4:
+            return ctx.hash_rows(pubs[None, :])[0]
+        st = np.zeros(12, dtype=np.uint64)
+        st[:pubs.size] = pubs
+        return ctx.poseidon(st[None, :])[0][:4]
+
+    def job(self, ctx, kind, pubs, key=0, degree_bits=None):
+        circ, wires = self.circuit(kind, key, degree_bits)
+        return self.state(ctx, kind, key, degree_bits), bind_public_inputs(circ, wires, self.public_inputs_hash(ctx, pubs)), pubs
+
+    # ---- ops.RecursionCircuits
+    def shrink_chain(self, table, air, log_n):
+        """the circuits of by_table[table].by_stark_size[log_n]: [("initial", key, bits), ("shrink", key, bits) ..]"""
+        if self.ranges is not None:
+            lo, hi = self.ranges[table]
+            if not lo <= log_n < hi:
+                raise KeyError("Missing preprocessed circuits for table %d with size %d." % (table, log_n))
+        bits = self.chain_degree_bits(air.n_trace_cols, air.n_aux_cols, log_n)
+        return [("initial" if i == 0 else "shrink", (table, log_n, i), b) for i, b in enumerate(bits)]
+
+    def initial_wrapper(self, ctx, table, air, log_n, stark_proof_words):
+        kind, key, bits = self.shrink_chain(table, air, log_n)[0]
+        pubs = np.concatenate([np.array([table, log_n], dtype=np.uint64), self.digest(ctx, stark_proof_words)])
+        return self.job(ctx, kind, pubs, key, bits)
+
+    def shrinking_wrapper(self, ctx, table, air, log_n, step, inner_proof):
+        kind, key, bits = self.shrink_chain(table, air, log_n)[step]
+        return self.job(ctx, kind, self.digest(ctx, inner_proof), key, bits)
+
+    def root(self, ctx, shrunk_proofs, stark_sizes):
+        pubs = np.concatenate([np.array(stark_sizes, dtype=np.uint64)] + [self.digest(ctx, p) for p in shrunk_proofs])
+        return self.job(ctx, "root", pubs)
 
     def aggregation(self, ctx, lhs, rhs):
         pubs = np.concatenate([self.digest(ctx, lhs.proof), self.digest(ctx, rhs.proof)])
-        return self.state(ctx, "agg"), self.witness(ctx, "agg", pubs), pubs
+        return self.job(ctx, "agg", pubs)
 
     def block(self, ctx, prev, agg, height=1):
         prev_d = self.digest(ctx, prev) if prev is not None else np.zeros(4, dtype=np.uint64)
         pubs = np.concatenate([np.array([height], dtype=np.uint64), self.digest(ctx, agg.proof), prev_d])
-        return self.state(ctx, "block"), self.witness(ctx, "block", pubs), pubs
+        return self.job(ctx, "block", pubs)
 
 
 # ------------------------------------------------------------------------------------------------ circuits of the recursion shape

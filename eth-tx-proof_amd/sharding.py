@@ -52,3 +52,111 @@ def gather_proofs(local_proofs, n_units, device=None, dst=0, group=None):
         for k, u in enumerate(shard_units(n_units, world, r)):
             res[u] = arr[k, 1:1 + int(arr[k, 0])].copy()
     return res
+
+
+class HandoffError(RuntimeError):
+    """a rank reported a failed map stage (or went silent): the whole job is given up, as paladin aborts on any FatalError"""
+
+
+_host_group_cache = {}
+
+
+def cached_host_group(timeout_s=1800):
+    """host_group() once per process (creating a group is itself a collective over all ranks)"""
+    from datetime import timedelta
+    key = (dist.get_world_size(), dist.get_rank())
+    if key not in _host_group_cache:
+        _host_group_cache[key] = dist.new_group(backend="gloo", timeout=timedelta(seconds=timeout_s))
+    return _host_group_cache[key]
+
+
+class Handoff:
+    """The hand-off of finished proofs to rank 0, OUT of the critical path: every worker rank hands each proof to a background sender
+    the moment it is done (`put`), rank 0 receives concurrently with its own proving, so that when the last unit finishes only that
+    unit's proof is still in flight.  The reference's map stage behaves the same way: a paladin worker returns each result as it
+    completes and the leader's fold consumes them (/root/reference/leader/src/prover.rs:26-30).
+
+    Protocol on the host (gloo) group, point to point: header [unit index, words, status] then the words; a rank's last message is
+    the marker [-1, 0, ok].  `finish(ok)` ends the stage on every rank: rank 0 waits for all markers, then ONE broadcast tells every
+    rank whether any map stage failed -- a rank that hit a FatalError no longer leaves the others blocked in a collective
+    (a rank that dies without a marker runs into the group's timeout).  Timings: `exposed_s` = what rank 0 waited in finish() after its
+    own last unit (the part of the hand-off that was NOT hidden behind proving), `bytes` = payload received."""
+
+    HDR_TAG, PAY_TAG = 11, 12
+
+    def __init__(self, n_units, group=None, dst=0):
+        import queue
+        import threading
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.n_units, self.dst = n_units, dst
+        self.group = group if (group is not None or self.world == 1) else cached_host_group()
+        self.res = [None] * n_units
+        self.bytes, self.exposed_s, self.error = 0, 0.0, None
+        self._q, self._th = queue.Queue(), None
+        if self.world > 1:
+            self._th = threading.Thread(target=self._recv_loop if self.rank == dst else self._send_loop, daemon=True)
+            self._th.start()
+
+    def put(self, unit, words):
+        """a finished proof (np.uint64 words) of unit `unit`; returns at once"""
+        if self.world == 1 or self.rank == self.dst:
+            self.res[unit] = np.array(words, dtype=np.uint64, copy=True)
+        else:
+            self._q.put((unit, np.array(words, dtype=np.uint64, copy=True)))
+
+    def _send_loop(self):
+        try:
+            while True:
+                unit, w = self._q.get()          # (unit, words) or the marker (None, ok)
+                if unit is None:
+                    dist.send(torch.tensor([-1, 0, 1 if w else 0], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
+                    return
+                dist.send(torch.tensor([unit, w.size, 1], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
+                dist.send(torch.from_numpy(w.view(np.int64)), self.dst, group=self.group, tag=self.PAY_TAG)
+        except Exception as e:          # surfaced by finish()
+            self.error = e
+
+    def _recv_loop(self):
+        try:
+            status, open_ranks = {}, self.world - 1
+            h = torch.zeros(3, dtype=torch.int64)
+            while open_ranks:
+                r = dist.recv(h, group=self.group, tag=self.HDR_TAG)          # from whichever rank has something (gloo: any source)
+                unit, n, ok = int(h[0]), int(h[1]), int(h[2])
+                if unit < 0:
+                    status[r] = ok
+                    open_ranks -= 1
+                    continue
+                buf = torch.empty(n, dtype=torch.int64)
+                dist.recv(buf, src=r, group=self.group, tag=self.PAY_TAG)
+                self.res[unit] = buf.numpy().view(np.uint64)
+                self.bytes += 8 * n
+            self._status = status
+        except Exception as e:
+            self.error = e
+
+    def finish(self, ok=True):
+        """Ends the stage.  Rank dst: the list of all proofs in unit order; other ranks: None.  Raises HandoffError on every rank when
+        any rank finished with ok=False."""
+        import time as _t
+        if self.world == 1:
+            if not ok:
+                raise HandoffError("map stage failed")
+            return self.res
+        t0 = _t.perf_counter()
+        if self.rank != self.dst:
+            self._q.put((None, bool(ok)))
+        self._th.join()
+        if self.error is not None:
+            raise HandoffError("proof hand-off failed: %s" % self.error)
+        self.exposed_s = _t.perf_counter() - t0
+        flag = torch.tensor([1], dtype=torch.int64)
+        if self.rank == self.dst:
+            bad = [r for r, s in self._status.items() if not s] + ([self.dst] if not ok else [])
+            missing = [u for u in range(self.n_units) if self.res[u] is None] if not bad else []
+            flag[0] = 0 if (bad or missing) else 1
+        dist.broadcast(flag, src=self.dst, group=self.group)
+        if int(flag[0]) != 1:
+            raise HandoffError("the map stage failed on a rank: every rank gives the job up")
+        return self.res if self.rank == self.dst else None

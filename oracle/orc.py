@@ -373,3 +373,83 @@ def prove_plonk(state, wires, public_inputs):
 def verify_plonk(state, public_inputs, proof):
     pub, proof = u64(public_inputs), u64(proof)
     return lib().orc_verify_plonk(C.byref(state.cfg), C.c_void_p(state.h), _p(pub), C.c_uint32(pub.size), _p(proof), C.c_size_t(proof.size))
+
+
+# ---- AllRecursiveCircuits::prove_root over stand-in circuits (checker of eth_tx_proof_amd.ops.prove_root)
+_plonk_states = {}
+
+
+def _plonk_state_for(rcfg, circ):
+    k = id(circ)
+    if k not in _plonk_states:
+        _plonk_states[k] = (circ, PlonkState(rcfg, circ))
+    return _plonk_states[k][1]
+
+
+def words_digest(words):
+    """the binding digest of a child proof (restated from plonk.SyntheticRecursion.digest): Merkle root over leaves of eight words"""
+    w = u64(words).ravel()
+    n_leaves = max(2, 1 << (max(1, -(-w.size // 8)) - 1).bit_length())
+    leaves = np.zeros((n_leaves, 8), dtype=np.uint64)
+    leaves.ravel()[:w.size] = w
+    return merkle_build(leaves, 0)[0][0]
+
+
+def _prove_bound(rcfg, circ, wires, pubs):
+    """one stand-in circuit: the PublicInputGate cells (row 0 of circ.pi_wires) carry hash_no_pad(public inputs)"""
+    pubs = u64(pubs)
+    w = np.array(wires, dtype=np.uint64, copy=True)
+    pih = hash_no_pad(pubs)
+    for k, col in enumerate(circ.pi_wires):
+        w[col, 0] = pih[k]
+    st = _plonk_state_for(rcfg, circ)
+    rc, p = prove_plonk(st, w, pubs)
+    assert rc == 0, rc
+    assert verify_plonk(st, pubs, p) == 0
+    return p
+
+
+def prove_root(cfg, rcfg, items, rec):
+    """The oracle's restatement of prove_root: STARK proofs of all tables (orc.prove), then per table the initial wrapper and the
+    shrinking wrappers, then the root proof.  `rec` supplies DATA only -- which circuits exist (rec.shrink_chain) and each circuit with
+    its witness (rec.circuit) -- the flow and the binding rule (public inputs = table index, size and Poseidon digests of the child
+    proofs' words) are restated here.  Returns (root proof, all_proof, [shrunk proofs])."""
+    rc, all_proof = prove(cfg, items)
+    assert rc == 0
+    shrunk, at = [], 2
+    for ti, it in enumerate(items):
+        n = proof_size_words(cfg, [it]) - 2
+        words = all_proof[at:at + n]
+        at += n
+        chain = rec.shrink_chain(ti, it[0], it[1])
+        kind, key, bits = chain[0]
+        circ, wires = rec.circuit(kind, key, bits)
+        proof = _prove_bound(rcfg, circ, wires, np.concatenate([np.array([ti, it[1]], dtype=np.uint64), words_digest(words)]))
+        for kind, key, bits in chain[1:]:
+            circ, wires = rec.circuit(kind, key, bits)
+            proof = _prove_bound(rcfg, circ, wires, words_digest(proof))
+        shrunk.append(proof)
+    assert at == all_proof.size
+    circ, wires = rec.circuit("root")
+    pubs = np.concatenate([np.array([it[1] for it in items], dtype=np.uint64)] + [words_digest(p) for p in shrunk])
+    return _prove_bound(rcfg, circ, wires, pubs), all_proof, shrunk
+
+
+def prove_block(cfg, rcfg, units, rec, height=1, prev=None):
+    """The whole job of /root/reference/leader/src/prover.rs:20-43 through the oracle: map(prove_root) over the units, balanced
+    pairwise fold with the aggregation circuit, block circuit.  -> (block proof, its public inputs, [root proofs])."""
+    roots = [prove_root(cfg, rcfg, items, rec)[0] for items in units]
+
+    def combine(a, b):
+        circ, wires = rec.circuit("agg")
+        return _prove_bound(rcfg, circ, wires, np.concatenate([words_digest(a), words_digest(b)]))
+    level = list(roots)
+    while len(level) > 1:
+        nxt = [combine(level[j], level[j + 1]) for j in range(0, len(level) - 1, 2)]
+        if len(level) & 1:
+            nxt.append(level[-1])
+        level = nxt
+    circ, wires = rec.circuit("block")
+    pubs = np.concatenate([np.array([height], dtype=np.uint64), words_digest(level[0]),
+                           words_digest(prev) if prev is not None else np.zeros(4, dtype=np.uint64)])
+    return _prove_bound(rcfg, circ, wires, pubs), pubs, roots

@@ -614,3 +614,145 @@ def _fri_prove(cfg, k, oracles, batches, ch):
             out += leaves[leaf] + _path(levels, leaf)
             x = leaf
     return out
+
+
+# ------------------------------------------------------------------------------------------------ Plonk prover (second restatement)
+def hash_pad(x):
+    """Hasher::hash_pad: x | 1 | 0.. | 1, padded to a multiple of the rate, through hash_no_pad (pad10*1)"""
+    p = [v % P for v in x] + [1]
+    while (len(p) + 1) % 8:
+        p.append(0)
+    p.append(1)
+    return hash_no_pad(p)
+
+
+def _gate_terms(instrs, consts, n_regs, local, pih):
+    """gate constraint terms of one point: OP 3 (EMIT) writes term (number of EMITs so far), OP 7 (EMIT_SLOT) term `dst`; terms add up"""
+    regs = [0] * max(1, n_regs)
+    out, seq = {}, 0
+
+    def val(o):
+        k, i = o >> 24, o & 0xFFFFFF
+        return regs[i] if k == 0 else local[i] if k == 1 else consts[i] % P if k == 3 else pih[i]
+    for op, dst, a, b in instrs:
+        x = val(a)
+        if op <= 2:
+            y = val(b)
+            regs[dst & 0xFFFFFF] = (x + y) % P if op == 0 else (x - y) % P if op == 1 else (x * y) % P
+        elif op == 3:
+            out[seq] = (out.get(seq, 0) + x) % P
+            seq += 1
+        else:
+            out[dst] = (out.get(dst, 0) + x) % P
+    return out
+
+
+def prove_plonk(cfg, circuit, wires, public_inputs):
+    """plonky2 plonk::prover::prove_with_partition_witness over a circuit given as data, in plain Python, written from the published
+    protocol separately from oracle/plonk.c.  cfg as in prove_tables; circuit: dict(degree_bits, num_wires, num_routed, qdf,
+    constants (cols x n), sigmas (cols x n), instrs, gate_constants, n_regs, domain_separator); wires: cols x n.
+    Returns the proof words in the layout of zk_prove_plonk."""
+    nch, rb, ch_h = cfg["num_challenges"], cfg["rate_bits"], cfg["cap_height"]
+    k, W, R, qdf = circuit["degree_bits"], circuit["num_wires"], circuit["num_routed"], circuit["qdf"]
+    n, lgL = 1 << k, k + rb
+    L = n << rb
+    g = MULTIPLICATIVE_GROUP_GENERATOR
+    consts, sigmas = circuit["constants"], circuit["sigmas"]
+    NC = len(consts)
+    assert qdf == 1 << rb and R % qdf == 0
+    nchunks = R // qdf
+    npp = nchunks - 1
+    # ---- CircuitBuilder::build (prover side): constants | sigmas commitment and the circuit digest
+    cs = commit_values([list(c) for c in consts] + [list(c) for c in sigmas], rb, ch_h)
+    digest = hash_no_pad([w for h in cs["cap"] for w in h] + hash_pad(circuit.get("domain_separator", [])) + [k])
+    out = [0x314B4C504C474B5A, k, W, R, NC]
+    wb = commit_values([[int(x) % P for x in c] for c in wires], rb, ch_h)
+    out += [w for h in wb["cap"] for w in h]
+    pih = hash_no_pad([int(x) % P for x in public_inputs])
+    ch = Challenger()
+    ch.observe_many(digest)
+    ch.observe_many(pih)
+    for h in wb["cap"]:
+        ch.observe_many(h)
+    betas = ch.get_n(nch)
+    gammas = ch.get_n(nch)
+    # ---- wires_permutation_partial_products_and_zs
+    w_n = root_of_unity(k)
+    ks = [pow(g, j, P) for j in range(R)]
+    zcols = [[0] * n for _ in range(nch)]
+    ppcols = [[[0] * n for _ in range(npp)] for _ in range(nch)]
+    for ci in range(nch):
+        z, x = 1, 1
+        for r in range(n):
+            zcols[ci][r] = z
+            acc = z
+            for c in range(nchunks):
+                num = den = 1
+                for t in range(qdf):
+                    j = c * qdf + t
+                    wv = int(wires[j][r]) % P
+                    num = num * ((wv + betas[ci] * ks[j] % P * x + gammas[ci]) % P) % P
+                    den = den * ((wv + betas[ci] * (int(sigmas[j][r]) % P) + gammas[ci]) % P) % P
+                acc = acc * num % P * inv(den) % P
+                if c < npp:
+                    ppcols[ci][c][r] = acc
+            z = acc
+            x = x * w_n % P
+    zpp = zcols + [col for ci in range(nch) for col in ppcols[ci]]
+    NZ = len(zpp)
+    zb = commit_values(zpp, rb, ch_h)
+    out += [w for h in zb["cap"] for w in h]
+    for h in zb["cap"]:
+        ch.observe_many(h)
+    alphas = ch.get_n(nch)
+    # ---- vanishing polynomial on the coset g<w_L>, divided by Z_H
+    w_L = root_of_unity(lgL)
+    sel = [0] * n
+    sel[0] = 1
+    l0 = coset_fft(ifft(sel) + [0] * (L - n), g)
+    gn = pow(g, n, P)
+    zh_inv = [inv((gn * pow(root_of_unity(rb), i, P) - 1) % P) for i in range(qdf)]
+    qv = [[0] * L for _ in range(nch)]
+    for i in range(L):
+        rl, rn = bitrev(i, lgL), bitrev((i + qdf) % L, lgL)
+        wr, zr, zn, cr = wb["leaves"][rl], zb["leaves"][rl], zb["leaves"][rn], cs["leaves"][rl]
+        x = g * pow(w_L, i, P) % P
+        terms = [l0[i] * (zr[ci] - 1) % P for ci in range(nch)]
+        for ci in range(nch):
+            for c in range(nchunks):
+                num = den = 1
+                for u in range(qdf):
+                    j = c * qdf + u
+                    num = num * ((wr[j] + betas[ci] * ks[j] % P * x + gammas[ci]) % P) % P
+                    den = den * ((wr[j] + betas[ci] * cr[NC + j] + gammas[ci]) % P) % P
+                prev = zr[ci] if c == 0 else zr[nch + ci * npp + c - 1]
+                nxt = zn[ci] if c == nchunks - 1 else zr[nch + ci * npp + c]
+                terms.append((prev * num - nxt * den) % P)
+        gt = _gate_terms(circuit["instrs"], circuit["gate_constants"], circuit["n_regs"], wr + cr[:NC], pih)
+        terms += [gt.get(t, 0) for t in range(max(gt) + 1 if gt else 0)]
+        for j in range(nch):
+            acc = 0
+            for t in reversed(terms):
+                acc = (acc * alphas[j] + t) % P
+            qv[j][i] = acc * zh_inv[i % qdf] % P
+    qco = []
+    for j in range(nch):
+        c = coset_ifft(qv[j], g)
+        qco += [c[s * n:(s + 1) * n] for s in range(qdf)]
+    qb = commit_coeffs(qco, rb, ch_h)
+    out += [w for h in qb["cap"] for w in h]
+    for h in qb["cap"]:
+        ch.observe_many(h)
+    zeta = ch.get_ext()
+    assert ext_pow(zeta, n) != (1, 0)
+    gz = ext_mul(zeta, (w_n, 0))
+    ev = lambda b, z: [poly_eval_ext(c, z) for c in b["coeffs"]]
+    o_cs, o_w, o_zpp, o_q = ev(cs, zeta), ev(wb, zeta), ev(zb, zeta), ev(qb, zeta)
+    o_zn = [poly_eval_ext(c, gz) for c in zb["coeffs"][:nch]]
+    flat = lambda es: [w for e in es for w in e]
+    # proof order: constants, sigmas, wires, zs, zs_next, partial products, quotient; transcript: the zeta batch, then zs_next
+    out += flat(o_cs) + flat(o_w) + flat(o_zpp[:nch]) + flat(o_zn) + flat(o_zpp[nch:]) + flat(o_q)
+    ch.observe_many(flat(o_cs) + flat(o_w) + flat(o_zpp[:nch]) + flat(o_zpp[nch:]) + flat(o_q))
+    ch.observe_many(flat(o_zn))
+    batches = [(zeta, cs["coeffs"] + wb["coeffs"] + zb["coeffs"] + qb["coeffs"]), (gz, zb["coeffs"][:nch])]
+    return out + _fri_prove(cfg, k, [cs, wb, zb, qb], batches, ch)

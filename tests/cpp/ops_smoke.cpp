@@ -1,5 +1,6 @@
 // Compiles and (on a GPU box) runs the C++ operator mirror: ops::set_prover_state_from_config + ops::TxProof::execute,
 // reading like the reference's call site (/root/reference/ops/src/lib.rs:29-61), then the caller's shape
+// (TxProof = prove_root: STARK proofs -> shrink chain -> root proof), then
 // ProverInput::prove = map(&TxProof).fold(&AggProof) -> BlockProof (/root/reference/leader/src/prover.rs:20-43) with a tiny
 // stand-in recursion circuit (identity permutation, no gates: any witness satisfies it).  Exit code 0 = proofs produced.
 #include <cstdio>
@@ -66,6 +67,14 @@ int main() {
     rec.aggregation = [](zk_ctx *ctx, const ops::AggregatableProof &a, const ops::AggregatableProof &b) {
         return tiny.job(ctx, {a.proof.size(), b.proof.size(), a.proof[1], b.proof[1]});
     };
+    // prove_root: the table's StarkProof goes through a chain of two wrappers (initial + one shrinking), then the root circuit
+    rec.shrink_chain_len = [](uint32_t, const zk_table &) { return 2u; };
+    rec.shrink_step = [](zk_ctx *ctx, uint32_t table, const zk_table &t, uint32_t step, const std::vector<uint64_t> &inner) {
+        return tiny.job(ctx, {table, t.log_n, step, inner.size(), inner[inner.size() / 2]});
+    };
+    rec.root = [](zk_ctx *ctx, const std::vector<std::vector<uint64_t>> &shrunk, const std::vector<zk_table> &tables) {
+        return tiny.job(ctx, {tables.size(), shrunk.size(), shrunk[0].size(), shrunk[0][7]});
+    };
     rec.block = [](zk_ctx *ctx, const std::vector<uint64_t> *prev, const ops::AggregatableProof &agg) {
         return tiny.job(ctx, {7 /* height */, agg.proof.size(), prev ? prev->size() : 0});
     };
@@ -76,7 +85,8 @@ int main() {
     try {
         ops::AggregatableProof p = ops::TxProof{}.execute(in);
         std::printf("proof words: %zu, magic %016llx\n", p.proof.size(), (unsigned long long)p.proof[0]);
-        if (p.proof[0] != 0x31465250474C4B5AULL) return 4;
+        if (p.proof[0] != 0x314B4C504C474B5AULL) return 4;                           // "ZKGLPLK1": the ROOT proof, a Plonk proof
+        if (ops::prove(in)[0] != 0x31465250474C4B5AULL) return 8;                    // "ZKGLPRF1": the STARK half alone
         ops::ProverInput job;
         for (int u = 0; u < 3; u++) job.proof_gen_ir.push_back(in);
         ops::GeneratedBlockProof blk = job.prove();

@@ -13,12 +13,19 @@ def test_txproof_execute(orc):
             ops.p_state()
         else:
             raise RuntimeError("Prover state is not initialized")
-    st = ops.set_prover_state_from_config(0)
+    st = ops.set_prover_state_from_config(0, stark_only=True)  # the STARK half alone, on explicit request
     assert ops.set_prover_state_from_config(0) is st          # second init keeps the first state
     prog = air.cpu_like_air(9, 2)
     tr, pub = orc.synth_trace(9, 7, 5)
     out = ops.TxProof().execute(ops.GenerationInputs([ops.TableInput(prog, 7, tr, pub)], txn_number_before=3, block_number=9))
     assert out.kind == "Txn"
+    old = ops.P_STATE
+    ops.P_STATE = ops.ProverState(0)                          # neither recursion circuits nor stark_only: prove_root cannot run
+    try:
+        with pytest.raises(ops.FatalError, match="no recursion circuits"):
+            ops.TxProof().execute(ops.GenerationInputs([ops.TableInput(prog, 7, tr, pub)]))
+    finally:
+        ops.P_STATE = old
     rc, ref = orc.prove(st.config, [(prog, 7, tr, pub)])
     assert rc == 0 and (out.proof == ref).all()
     assert orc.verify(st.config, [(prog, 7, None, pub)], out.proof) == 0
@@ -39,53 +46,71 @@ def test_cpp_operator_mirror_runs(zk, tmp_path):
     assert "proof words" in rc.stdout
 
 
-def test_prover_input_map_fold_block(orc):
-    """The caller of the operators, /root/reference/leader/src/prover.rs:20-43: map(&TxProof) over five units on three worker
-    threads, fold(&AggProof) pairwise, BlockProof on the result -- every proof on the GPU (STARK prover for the units, Plonk prover
-    for the fold and the block).  The recursion circuits are the synthetic stand-ins of plonk.SyntheticRecursion (the real ones are
-    an input), so what is checked is the flow and the proofs: each stage equals the oracle's proof of the same
-    statement bit for bit and the oracle's verifiers accept."""
-    from eth_tx_proof_amd import air, leader, ops, plonk
+def _small_tables(orc, seed0, shapes=((165, 7), (21, 8), (9, 6))):
+    from eth_tx_proof_amd import air, ops
+    tabs, items = [], []
+    for t, (w, lg) in enumerate(shapes):
+        prog = air.cpu_like_air(w, min(19, w // 4))
+        tr, pub = orc.synth_trace(w, lg, seed0 + t)
+        tabs.append(ops.TableInput(prog, lg, tr, pub))
+        items.append((prog, lg, tr, pub))
+    return tabs, items
+
+
+def test_txproof_is_the_whole_prove_root(orc):
+    """TxProof.execute = generate_txn_proof = AllRecursiveCircuits::prove_root (/root/reference/ops/src/lib.rs:52): the STARK proofs of
+    all tables, per table the initial wrapper and the shrinking wrappers (until degree_bits <= threshold), then the root proof -- every
+    proof on the GPU, and the root proof, the shrunk proofs' chain and the STARK proofs equal the oracle's restatement of the same flow
+    (orc.prove_root) word for word.  Circuits: plonk.SyntheticRecursion stand-ins (recursion-shaped gate set, reduced sizes)."""
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import ops, plonk
     old = ops.P_STATE
     ops.P_STATE = None
     try:
-        rec = plonk.SyntheticRecursion(degree_bits=7, seed=3)
+        rec = plonk.SyntheticRecursion(size_shift=-6, threshold=6, seed=2)
         st = ops.set_prover_state_from_config(0, recursion=rec)
-        prog = air.cpu_like_air(9, 2)
-        units, traces = [], []
+        tabs, items = _small_tables(orc, 40)
+        chains = [[b for _, _, b in rec.shrink_chain(t, it[0], it[1])] for t, it in enumerate(items)]
+        assert chains == [[7, 6], [6], [6]]                   # a chain with a shrinking wrapper and two without
+        timing = {}
+        root, pv, all_proof = ops.prove_root(ops.GenerationInputs(tabs), timing)
+        ref_root, ref_all, ref_shrunk = orc.prove_root(st.config, rec.cfg, items, rec)
+        assert (all_proof == ref_all).all()
+        assert root.size == ref_root.size and (root == ref_root).all()
+        assert set(timing) == {"stark_s", "shrink_s", "root_s"}
+        out = ops.TxProof().execute(ops.GenerationInputs(tabs))
+        assert out.kind == "Txn" and (out.proof == ref_root).all() and len(out.public_values) == 3
+        # a size no circuits were built for is fatal, as upstream's "Missing preprocessed circuits"
+        st.recursion = plonk.SyntheticRecursion(size_shift=-6, threshold=6, seed=2, degree_bits_ranges=[(8, 9)] * 3)
+        with pytest.raises(ops.FatalError, match="Missing preprocessed circuits for table 0 with size 7"):
+            ops.TxProof().execute(ops.GenerationInputs(tabs))
+    finally:
+        ops.P_STATE = old
+
+
+def test_prover_input_map_fold_block(orc):
+    """The caller of the operators, /root/reference/leader/src/prover.rs:20-43: map(&TxProof) over five units on three worker
+    threads (each unit = prove_root: STARK proofs, shrink chains, root proof), fold(&AggProof) pairwise, BlockProof on the result --
+    every proof on the GPU.  The recursion circuits are the stand-ins of plonk.SyntheticRecursion (the real ones are an input,
+    SURVEY.md A10), so what is checked is the flow and the proofs: the block proof equals the oracle's for the whole job bit for bit
+    and the oracle's verifier accepts."""
+    from eth_tx_proof_amd import leader, ops, plonk
+    old = ops.P_STATE
+    ops.P_STATE = None
+    try:
+        rec = plonk.SyntheticRecursion(size_shift=-7, threshold=5, seed=3)
+        st = ops.set_prover_state_from_config(0, recursion=rec)
+        units, unit_items = [], []
         for u in range(5):
-            tr, pub = orc.synth_trace(9, 7, 100 + u)
-            traces.append((tr, pub))
-            units.append(ops.GenerationInputs([ops.TableInput(prog, 7, tr, pub)], txn_number_before=u, block_number=1))
+            tabs, items = _small_tables(orc, 100 + 10 * u, shapes=((9, 7), (12, 6)))
+            units.append(ops.GenerationInputs(tabs, txn_number_before=u, block_number=1))
+            unit_items.append(items)
         rt = leader.Runtime(num_workers=3)
         block = leader.ProverInput(units).prove(rt)
         assert rt.requeued == []
-        # ---- the same job through the oracle
-        proofs = []
-        for tr, pub in traces:
-            rc, p = orc.prove(st.config, [(prog, 7, tr, pub)])
-            assert rc == 0
-            proofs.append(p)
-        dig = lambda w: orc.hash_rows(np.ascontiguousarray(w)[None, :])[0]
-        agg_state = orc.PlonkState(rec.cfg, rec.circuits["agg"][0])
-        blk_state = orc.PlonkState(rec.cfg, rec.circuits["block"][0])
-
-        def combine(a, b):
-            pubs = np.concatenate([dig(a), dig(b)])
-            rc, p = orc.prove_plonk(agg_state, plonk.bind_public_inputs(*rec.circuits["agg"], dig(pubs)), pubs)
-            assert rc == 0 and orc.verify_plonk(agg_state, pubs, p) == 0
-            return p
-        level = proofs
-        while len(level) > 1:       # the same balanced tree as Runtime.fold
-            nxt = [combine(level[j], level[j + 1]) for j in range(0, len(level) - 1, 2)]
-            if len(level) & 1:
-                nxt.append(level[-1])
-            level = nxt
-        pubs = np.concatenate([np.array([1], dtype=np.uint64), dig(level[0]), np.zeros(4, dtype=np.uint64)])
-        rc, ref = orc.prove_plonk(blk_state, plonk.bind_public_inputs(*rec.circuits["block"], dig(pubs)), pubs)
-        assert rc == 0
-        assert block.b_height == 1 and (block.intern == ref).all()
-        assert orc.verify_plonk(blk_state, pubs, block.intern) == 0
+        ref, pubs, _ = orc.prove_block(st.config, rec.cfg, unit_items, rec)
+        assert block.b_height == 1 and block.intern.size == ref.size and (block.intern == ref).all()
+        assert orc.verify_plonk(orc._plonk_state_for(rec.cfg, rec.circuit("block")[0]), pubs, block.intern) == 0
         # one unit folds to a Txn proof, which the reference refuses (prover.rs:41)
         with pytest.raises(RuntimeError, match="not GeneratedAggProof"):
             leader.ProverInput(units[:1]).prove(rt)
@@ -100,7 +125,7 @@ def test_failed_unit_is_requeued_once(orc, monkeypatch):
     old = ops.P_STATE
     ops.P_STATE = None
     try:
-        ops.set_prover_state_from_config(0)
+        ops.set_prover_state_from_config(0, stark_only=True)
         prog = air.cpu_like_air(9, 2)
         units = []
         for u in range(4):

@@ -56,3 +56,103 @@ def test_oracle_plonk_refuses_malformed_circuits(orc):
     with pytest.raises(ValueError):
         orc.PlonkState(cfg, circ)
     assert orc.plonk_proof_size_words(cfg, circ) == 0
+
+
+@pytest.mark.parametrize("degree_bits,kind", [(3, "synthetic"), (4, "synthetic"), (5, "recursion")])
+def test_c_oracle_plonk_proof_equals_the_pure_python_restatement(orc, degree_bits, kind):
+    """oracle/plonk.c (C) and oracle/pyspec.py::prove_plonk (plain Python, written separately) produce the same proof words: a second
+    restatement of the whole Plonk transcript -- circuit digest with the padded domain separator, partial products and Z, the
+    order of the vanishing-polynomial terms (gate terms adding up per index), reduce_with_powers, quotient chunks, opening and
+    observation order, the four-oracle FRI instance.  Reduced FRI parameters keep the pure-Python prover within seconds; parity
+    with upstream stays unpinned."""
+    import pyspec
+    from eth_tx_proof_amd import plonk
+    from eth_tx_proof_amd._abi import StarkConfig
+    cfg = StarkConfig(100, 2, 3, 2, 3, 4, 5, 3)          # rate_bits 3, cap_height 2, PoW 3 bits, 3 query rounds
+    if kind == "synthetic":
+        circ, wires = plonk.synthetic_circuit(degree_bits=degree_bits, num_wires=40, num_routed=16, n_muladd=6, n_sbox=4, seed=degree_bits,
+                                              public_input_gate=True)
+        sep = [5, 6, 7]
+        pi_wires = circ.pi_wires
+        circ = plonk.Circuit(circ.degree_bits, circ.num_wires, circ.num_routed, circ.constants, circ.sigmas, circ.gates, domain_separator=sep)
+        circ.pi_wires = pi_wires
+    else:
+        circ, wires = plonk.recursion_circuit(degree_bits=degree_bits, seed=9)
+        sep = []
+    pubs = np.array([11, 12, 13, 14, 15], dtype=np.uint64)
+    wires = plonk.bind_public_inputs(circ, wires, orc.hash_no_pad(pubs))
+    st = orc.PlonkState(cfg, circ)
+    rc, ref = orc.prove_plonk(st, wires, pubs)
+    assert rc == 0 and orc.verify_plonk(st, pubs, ref) == 0
+    pcfg = dict(num_challenges=2, rate_bits=3, cap_height=2, proof_of_work_bits=3, fri_arity_bits=4, fri_final_poly_bits=5, num_query_rounds=3)
+    g = circ.gates
+    pc = dict(degree_bits=circ.degree_bits, num_wires=circ.num_wires, num_routed=circ.num_routed, qdf=8,
+              constants=[[int(x) for x in c] for c in circ.constants], sigmas=[[int(x) for x in c] for c in circ.sigmas],
+              instrs=[(i.op, i.dst, i.a, i.b) for i in g._instrs[:g.n_instrs]], gate_constants=[int(x) for x in g._constants],
+              n_regs=g.air.n_regs, domain_separator=sep)
+    got = pyspec.prove_plonk(pcfg, pc, [[int(x) for x in c] for c in wires], [int(x) for x in pubs])
+    assert len(got) == ref.size
+    diff = [i for i, (a, b) in enumerate(zip(got, ref)) if a != int(b)]
+    assert not diff, "first differing word %d of %d" % (diff[0], len(got))
+    assert [int(x) for x in st.digest()] == pyspec.hash_no_pad([w for h in pyspec.commit_values(pc["constants"] + pc["sigmas"], 3, 2)["cap"] for w in h]
+                                                              + pyspec.hash_pad(sep) + [circ.degree_bits])
+
+
+def test_recursion_shaped_gate_set(orc):
+    """gates.py: eight gates in upstream's (degree, id) order, three selector groups under max degree 8, 123 gate terms (PoseidonGate's
+    count), every constraint of every gate zero on the witness of `recursion_circuit`, and the PoseidonGate rows compute the permutation."""
+    from eth_tx_proof_amd import gates as GT, plonk, poseidon_tables as PT
+    assert GT.selector_groups() == [(0, 5), (5, 7), (7, 8)]
+    circ, w = plonk.recursion_circuit(degree_bits=7, seed=4)
+    prog, _ = GT.gate_program(135)
+    ins = [(i.op, i.dst, i.a, i.b) for i in prog._instrs[:prog.n_instrs]]
+    consts = [int(x) for x in prog._constants]
+    assert max(d for op, d, _, _ in ins if op == 7) + 1 == 123
+    pih = [int(x) for x in orc.hash_no_pad(np.array([1, 2], dtype=np.uint64))]
+    w2 = plonk.bind_public_inputs(circ, w, pih)
+    seen = set()
+    for r in range(128):
+        out = GT.eval_program_row(ins, consts, w2[:, r], circ.constants[:, r], pih, 135)
+        assert not [t for t, v in out.items() if v], (r, int(circ.gate_of_row[r]))
+        seen.add(int(circ.gate_of_row[r]))
+    assert seen == set(range(8))
+    r = int(circ.gate_rows["PoseidonGate"][1])
+    inp = [int(x) for x in w[0:12, r]]
+    if int(w[24, r]):
+        inp = inp[4:8] + inp[0:4] + inp[8:]
+    assert orc.poseidon(np.array(inp, dtype=np.uint64)).tolist() == [int(x) for x in w[12:24, r]]
+    # a broken PoseidonGate wire is caught by the verifier of the oracle
+    import eth_tx_proof_amd as E
+    cfg = E.standard_recursion_config()
+    st = orc.PlonkState(cfg, circ)
+    pubs = np.array([1, 2], dtype=np.uint64)
+    rc, p = orc.prove_plonk(st, w2, pubs)
+    assert rc == 0 and orc.verify_plonk(st, pubs, p) == 0
+    bad = w2.copy(); bad[70, r] ^= np.uint64(1)
+    rc, p = orc.prove_plonk(st, bad, pubs)
+    assert rc == 0 and orc.verify_plonk(st, pubs, p) == 220
+    bad = w2.copy(); bad[0, int(circ.gate_rows["PoseidonGate"][-1])] ^= np.uint64(1)      # chained input: breaks the copy constraint too
+    rc, p = orc.prove_plonk(st, bad, pubs)
+    assert rc == 0 and orc.verify_plonk(st, pubs, p) != 0
+
+
+def test_oracle_prove_root_flow(orc):
+    """orc.prove_root / prove_block (the checker of ops.prove_root and leader.ProverInput.prove): chains with and without a shrinking
+    wrapper, every proof accepted by the verifier, the root proof bound to its children through its public inputs."""
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import air, plonk
+    cfg, rcfg = E.standard_fast_config(), E.standard_recursion_config()
+    rec = plonk.SyntheticRecursion(size_shift=-7, threshold=5, seed=8)
+    items = []
+    for t, (w, lg) in enumerate(((165, 7), (9, 6))):
+        prog = air.cpu_like_air(w, min(19, w // 4))
+        tr, pub = orc.synth_trace(w, lg, 70 + t)
+        items.append((prog, lg, tr, pub))
+    assert [[b for _, _, b in rec.shrink_chain(t, it[0], it[1])] for t, it in enumerate(items)] == [[6, 5], [5]]
+    root, all_proof, shrunk = orc.prove_root(cfg, rcfg, items, rec)
+    assert orc.verify(cfg, [(p, lg, None, pub) for p, lg, _, pub in items], all_proof) == 0
+    pubs = np.concatenate([np.array([7, 6], dtype=np.uint64)] + [orc.words_digest(s) for s in shrunk])
+    st = orc._plonk_state_for(rcfg, rec.circuit("root")[0])
+    assert orc.verify_plonk(st, pubs, root) == 0
+    other = pubs.copy(); other[3] ^= np.uint64(1)                  # another child digest: the root proof does not verify against it
+    assert orc.verify_plonk(st, other, root) != 0

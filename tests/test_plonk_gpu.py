@@ -102,16 +102,6 @@ def test_plonk_circuit_shape_sweep_bit_exact(ctx, zk, orc, k, num_wires, num_rou
         st.free()
 
 
-def test_plonk_more_than_sixteen_chunks_is_refused(ctx, zk):
-    """include/zkgl.h: at most 16 chunks of routed wires (128 at quotient degree factor 8) -- a documented limit of this prover, not
-    of upstream: refused with ZK_ERR_INVALID_ARG, loudly, before any work."""
-    from eth_tx_proof_amd import plonk
-    circ, _ = plonk.synthetic_circuit(degree_bits=4, num_wires=160, num_routed=136, n_muladd=2, n_sbox=1, seed=1)
-    with pytest.raises(zk.ZkError) as e:
-        zk.PlonkState(ctx, _cfg(), circ)
-    assert e.value.code == -1
-
-
 def test_public_input_gate_binds_the_proof_to_its_public_inputs(ctx, zk, orc):
     """A circuit with upstream's PublicInputGate (PUBLIC operands = the words of public_inputs_hash): same proof as the oracle, accepted;
     the same proof under other public inputs, and a witness that does not carry the hash, are rejected."""
@@ -132,5 +122,59 @@ def test_public_input_gate_binds_the_proof_to_its_public_inputs(ctx, zk, orc):
         other = pub.copy(); other[0] += np.uint64(1)
         assert orc.verify_plonk(ost, other, proof) != 0
         assert orc.verify_plonk(ost, pub, zk.prove_plonk(st, wires, pub)) != 0          # witness without the hash in the gate's wires
+    finally:
+        st.free()
+
+
+@pytest.mark.parametrize("degree_bits,seed", [(5, 21), (8, 11), (11, 22), (13, 12)])
+def test_recursion_shaped_circuit_bit_exact_vs_oracle(ctx, zk, orc, degree_bits, seed):
+    """The gate load of the real recursion circuits (gates.py: PoseidonGate's 123 degree-7 constraints + arithmetic / reducing / base-sum
+    gates behind selector filters, gate terms adding up per index, 29 program registers): GPU proof == oracle proof, word for word; the
+    2^8 and 2^13 cases also against the digests committed in tests/golden/proof_digests.json."""
+    import hashlib, json, os
+    from eth_tx_proof_amd import plonk
+    cfg = _cfg()
+    circ, wires = plonk.recursion_circuit(degree_bits=degree_bits, seed=seed)
+    pub = np.array([degree_bits, seed, 7], dtype=np.uint64)
+    wires = plonk.bind_public_inputs(circ, wires, orc.hash_no_pad(pub))
+    ost = orc.PlonkState(cfg, circ)
+    st = zk.PlonkState(ctx, cfg, circ)
+    try:
+        assert (st.digest() == ost.digest()).all()
+        proof = zk.prove_plonk(st, wires, pub)
+        rc, ref = orc.prove_plonk(ost, wires, pub)
+        assert rc == 0 and proof.size == ref.size
+        if not (proof == ref).all():
+            bad = np.nonzero(proof != ref)[0]
+            pytest.fail("first differing word %d of %d (%d differ)" % (bad[0], proof.size, bad.size))
+        assert orc.verify_plonk(ost, pub, proof) == 0
+        gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proof_digests.json")))["recursion_plonk_proofs"]
+        for g in gold:
+            if g["degree_bits"] == degree_bits and g["seed"] == seed:
+                assert hashlib.sha256(proof.tobytes()).hexdigest() == g["sha256"]
+        # another context of the same device proves with the same prover data (P_STATE is shared by all workers)
+        other = zk.Context(0)
+        try:
+            assert (zk.prove_plonk(st, wires, pub, ctx=other) == proof).all()
+        finally:
+            other.close()
+    finally:
+        st.free()
+
+
+def test_wide_routing_and_domain_separator(ctx, zk, orc):
+    """More routed wires than 16 chunks of the quotient degree factor (the former limit: 128) and a non-empty domain separator."""
+    from eth_tx_proof_amd import plonk
+    cfg = _cfg()
+    circ, wires = plonk.synthetic_circuit(degree_bits=7, num_wires=200, num_routed=152, seed=31)
+    circ = plonk.Circuit(circ.degree_bits, circ.num_wires, circ.num_routed, circ.constants, circ.sigmas, circ.gates, domain_separator=[3, 1, 4, 1, 5, 9, 2, 6, 5])
+    pub = np.array([1], dtype=np.uint64)
+    ost = orc.PlonkState(cfg, circ)
+    st = zk.PlonkState(ctx, cfg, circ)
+    try:
+        assert (st.digest() == ost.digest()).all()
+        proof = zk.prove_plonk(st, wires, pub)
+        rc, ref = orc.prove_plonk(ost, wires, pub)
+        assert rc == 0 and (proof == ref).all() and orc.verify_plonk(ost, pub, proof) == 0
     finally:
         st.free()

@@ -45,6 +45,58 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert "GATHER_OK" in out.stdout
 
 
+HANDOFF_WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, %r)
+    import numpy as np, torch.distributed as dist
+    import eth_tx_proof_amd
+    from eth_tx_proof_amd import sharding
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_units = 7
+    standin = lambda u: np.full(50 + 11 * u, 7000 + u, dtype=np.uint64) + np.arange(50 + 11 * u, dtype=np.uint64)
+    # ---- proofs handed over one by one while the 'proving' goes on; rank 0 only waits for what is still in flight at the end
+    ho = sharding.Handoff(n_units)                 # group None: the cached host (gloo) group
+    for u in sharding.shard_units(n_units, world, rank):
+        time.sleep(0.05)                            # the next unit is being proved
+        ho.put(u, standin(u))
+    got = ho.finish(ok=True)
+    if rank == 0:
+        assert len(got) == n_units and all((got[u] == standin(u)).all() for u in range(n_units))
+        assert ho.bytes == sum(8 * standin(u).size for u in sharding.shard_units(n_units, world, 1))
+        assert ho.exposed_s < 0.04, ho.exposed_s    # the hand-off hid behind the proving
+    else:
+        assert got is None
+    # ---- a rank whose map stage failed: EVERY rank raises instead of waiting for proofs that never come
+    ho = sharding.Handoff(n_units)
+    mine = sharding.shard_units(n_units, world, rank)
+    for u in mine[:1]:
+        ho.put(u, standin(u))
+    try:
+        ho.finish(ok=(rank != 1))
+        raised = False
+    except sharding.HandoffError:
+        raised = True
+    assert raised
+    dist.barrier()
+    print("HANDOFF_OK_%%d" %% rank)
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_two_rank_overlapped_handoff_and_failure_propagation(tmp_path):
+    """sharding.Handoff (what leader.ProverInput.prove and bench.py --gpus N use): per-proof sends from a background thread, receive
+    loop on rank 0, one status broadcast at the end so that a failed rank cannot leave the others blocked."""
+    script = tmp_path / "handoff_worker.py"
+    script.write_text(HANDOFF_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "HANDOFF_OK_0" in out.stdout and "HANDOFF_OK_1" in out.stdout
+
+
 def test_shard_units_cover_everything_once():
     sys.path.insert(0, ROOT)
     import eth_tx_proof_amd  # noqa: F401
@@ -83,7 +135,7 @@ def test_runtime_map_requeues_device_errors_once():
     old = ops.P_STATE
     ops.P_STATE = None
     try:
-        ops.set_prover_state_from_config(0)
+        ops.set_prover_state_from_config(0, stark_only=True)
 
         class Op:
             def __init__(self, fail_unit, times, code):

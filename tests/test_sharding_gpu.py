@@ -101,41 +101,23 @@ LEADER_WORKER = textwrap.dedent("""
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     orc.lib().orc_set_threads(8)
-    rec = plonk.SyntheticRecursion(degree_bits=7, seed=5)
+    rec = plonk.SyntheticRecursion(size_shift=-7, threshold=4, seed=5)
     st = ops.set_prover_state_from_config(0, recursion=rec)
     prog = air.cpu_like_air(9, 2)
-    units, traces = [], []
+    units, unit_items = [], []
     for u in range(6):                                     # every rank holds the job description (the reference's proof_gen_ir)
         tr, pub = orc.synth_trace(9, 8, 300 + u)
-        traces.append((tr, pub))
+        unit_items.append([(prog, 8, tr, pub)])
         units.append(ops.GenerationInputs([ops.TableInput(prog, 8, tr, pub)], txn_number_before=u, block_number=1))
+    assert [b for _, _, b in rec.shrink_chain(0, prog, 8)] == [5, 5]      # initial wrapper + one shrinking wrapper per unit
     block = leader.ProverInput(units).prove(leader.Runtime(num_workers=2), group=sharding.host_group())
     if rank != 0:
         assert block is None
     else:
-        # the same job through the oracle, single process: unit proofs, the balanced fold, the block proof
-        dig = lambda w: orc.hash_rows(np.ascontiguousarray(w)[None, :])[0]
-        level = []
-        for tr, pub in traces:
-            rc, p = orc.prove(st.config, [(prog, 8, tr, pub)])
-            assert rc == 0
-            level.append(p)
-        agg_state = orc.PlonkState(rec.cfg, rec.circuits["agg"][0])
-        blk_state = orc.PlonkState(rec.cfg, rec.circuits["block"][0])
-        def combine(a, b):
-            pubs = np.concatenate([dig(a), dig(b)])
-            rc, p = orc.prove_plonk(agg_state, plonk.bind_public_inputs(*rec.circuits["agg"], dig(pubs)), pubs)
-            assert rc == 0
-            return p
-        while len(level) > 1:
-            nxt = [combine(level[j], level[j + 1]) for j in range(0, len(level) - 1, 2)]
-            if len(level) & 1:
-                nxt.append(level[-1])
-            level = nxt
-        pubs = np.concatenate([np.array([1], dtype=np.uint64), dig(level[0]), np.zeros(4, dtype=np.uint64)])
-        rc, ref = orc.prove_plonk(blk_state, plonk.bind_public_inputs(*rec.circuits["block"], dig(pubs)), pubs)
-        assert rc == 0 and (block.intern == ref).all() and block.b_height == 1
-        assert orc.verify_plonk(blk_state, pubs, block.intern) == 0
+        # the same job through the oracle, single process: prove_root per unit, the balanced fold, the block proof
+        ref, pubs, _ = orc.prove_block(st.config, rec.cfg, unit_items, rec)
+        assert (block.intern == ref).all() and block.b_height == 1
+        assert orc.verify_plonk(orc._plonk_state_for(rec.cfg, rec.circuit("block")[0]), pubs, block.intern) == 0
         print("LEADER_OK")
     dist.barrier()
     dist.destroy_process_group()
