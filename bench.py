@@ -51,7 +51,94 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host-resident traces) measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled repeat (no kernel table / roofline)")
+    ap.add_argument("--workload", choices=["stark_unit", "prove_root"], default="stark_unit",
+                    help="stark_unit (default, BASELINE's metric): one unit STARK proof per step and worker.  prove_root: one TRANSACTION end to end "
+                         "per step and worker -- BASELINE configs[3]'s seven tables, their shrink chains and the root proof (TxProof.execute)")
     return ap.parse_args()
+
+
+def bench_prove_root(args):
+    """--workload prove_root: what one call of the reference's operator does (/root/reference/ops/src/lib.rs:52, generate_txn_proof =
+    prove_root): the STARK proofs of the seven tables at configs[3]'s sizes, every table's initial wrapper and shrinking wrappers, the
+    root proof -- all on the GPU, recursion circuits = plonk.SyntheticRecursion's stand-ins at the estimated sizes of the real ones.
+    One GPU; a step = `--inflight` transactions, one worker thread + context each.  Never the default: BASELINE's metric is the unit."""
+    import numpy as np
+    import torch
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import air, lib as zl, ops, plonk
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        sys.exit("bench.py --workload prove_root: one GPU only (transactions shard over ranks exactly like the units of the default workload)")
+    inflight = args.inflight or 4
+    rec = plonk.SyntheticRecursion()
+    st = ops.set_prover_state_from_config(0, recursion=rec)
+
+    def unit(ctx):
+        tabs = []
+        for t, (w, lg) in enumerate(zip(air.ZKEVM_TABLE_WIDTHS, air.ZKEVM_CFG4_LOG_SIZES)):
+            d, pub = zl.synth_trace_dev(ctx, w, lg, 0x5EED0000 + 1000 * t)
+            tabs.append(ops.TableInput(air.cpu_like_air(w, min(19, w // 4)), lg, d, pub))
+        return ops.GenerationInputs(tabs)
+    ctx0 = st.ctx()
+    u0 = unit(ctx0)
+    chains = [[b for _, _, b in rec.shrink_chain(t, tb.air, tb.log_n)] for t, tb in enumerate(u0.tables)]
+    st.prepare(u0.tables)                      # constraint kernels of the wide tables (hiprtc or the prover-state directory): start-up work
+    root0, _, all0 = ops.prove_root(u0)        # builds every circuit's prover data: start-up work too
+    split = {"stark_s": 0.0, "shrink_s": 0.0, "root_s": 0.0}
+    reps = 3
+    for _ in range(reps):
+        tm = {}
+        r, _, _ = ops.prove_root(u0, tm)
+        assert np.array_equal(r, root0)
+        for k in split:
+            split[k] += tm[k] / reps
+    ctx0.profile(True); ctx0.profile_reset()
+    ops.prove_root(u0)
+    rep = ctx0.profile_report()
+    ctx0.profile(False)
+    errs = []
+    go, done = threading.Barrier(inflight + 1), threading.Barrier(inflight + 1)
+
+    def worker(s):
+        try:
+            u = unit(st.ctx())
+            for _ in range(max(1, args.warmup)):
+                ops.prove_root(u)
+            go.wait()
+            for _ in range(args.steps):
+                r = ops.prove_root(u)[0]
+            if not np.array_equal(r, root0):
+                raise RuntimeError("worker %d: another root proof than the first unit's" % s)
+            done.wait()
+        except Exception as e:
+            errs.append(e)
+            go.abort(); done.abort()
+    th = [threading.Thread(target=worker, args=(s,)) for s in range(inflight)]
+    for t in th:
+        t.start()
+    go.wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
+    n_tx = args.steps * inflight
+    kern = {k: {"launches_per_tx": l, "ms_per_tx_alone": round(ms, 3)} for k, (l, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])[:14] if not k.startswith("phase: ")}
+    print(json.dumps({
+        "metric": "transaction root proofs/sec (prove_root: 7 table STARKs + shrink chains + root proof)", "value": n_tx / dt, "unit": "tx/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 (Goldilocks field)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3] end to end: seven tables (log sizes %s, widths %s) on one challenger, shrink chains %s (degree bits), "
+                               "root 2^%d; recursion circuits: stand-ins of the recursion shape (plonk.SyntheticRecursion), standard_recursion_config"
+                               % (list(air.ZKEVM_CFG4_LOG_SIZES), list(air.ZKEVM_TABLE_WIDTHS), chains, rec._bits(rec.ROOT_BITS)),
+                   "tx_per_step_per_gpu": inflight, "parallelism": "independent transactions, 1 GPU"},
+        "one_tx_alone_ms": {"total": sum(split.values()) * 1e3, "stark_proofs": split["stark_s"] * 1e3,
+                            "shrink_chains_%d_plonk_proofs" % sum(len(c) for c in chains): split["shrink_s"] * 1e3, "root_proof": split["root_s"] * 1e3},
+        "kernels_one_tx_alone": kern, "roofline": None, "cpu_baseline": None,
+        "note": "not BASELINE's metric (that is the default workload); roofline / cpu_baseline are reported by the default workload"}))
 
 
 def fan_out(args):
@@ -181,6 +268,8 @@ def int_alu_peak():
 
 def main():
     args = parse_args()
+    if args.workload == "prove_root":
+        return bench_prove_root(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(fan_out(args))

@@ -330,15 +330,36 @@ int32_t zk_scale_cols(zk_ctx *ctx, u64 *data, size_t stride, int k, int n_cols, 
 }
 
 // ------------------------------------------------------------------ C ABI: fft_with_options / ifft_with_options / coset variants
-extern "C" int32_t zk_ntt_batch_dev(zk_ctx *ctx, uint64_t *d_data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift) {
-    if (!ctx || !d_data || log_n > 30 || n_cols == 0) return ZK_ERR_INVALID_ARG;
+__global__ void ntt_zero_tail_kernel(u64 *d, size_t n, size_t keep, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total && (i & (n - 1)) >= keep) d[i] = 0;
+}
+// fft_with_options / ifft_with_options with zero_factor = Some(r): the caller promises that only the first n >> r inputs of every column are
+// non-zero, and upstream then skips the first r butterfly layers (they would only copy) -- i.e. it computes the transform of the input
+// with its tail TAKEN AS zero.  Forward: the size-n transform of zero-padded coefficients is 2^r transforms of size n >> r on the cosets
+// shift * w_n^par (the same identity the commit path uses for its LDE), each written where the bit-reversed order wants it.
+extern "C" int32_t zk_ntt_batch_opts_dev(zk_ctx *ctx, uint64_t *d_data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift, uint32_t zero_factor) {
+    if (!ctx || !d_data || log_n > 30 || n_cols == 0 || zero_factor > log_n) return ZK_ERR_INVALID_ARG;
     hipSetDevice(ctx->device);
     size_t n = (size_t)1 << log_n;
     shift = gl_canon(shift);
     u64 *tmp = (u64 *)ctx->alloc(n * n_cols * sizeof(u64));
     if (!tmp) return ZK_ERR_OOM;
-    int32_t rc;
-    if (!inverse) {
+    int32_t rc = ZK_OK;
+    if (zero_factor && inverse) {       // rare: give the ignored tail its promised value, then the full inverse transform
+        const size_t total = n * n_cols;
+        ZK_LAUNCH(ctx, "ntt_zero_tail", ntt_zero_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (u64 *)d_data, n, n >> zero_factor, total);
+    }
+    if (!inverse && zero_factor) {
+        const u32 r = zero_factor, ks = log_n - r;
+        const size_t ns = n >> r;
+        const u64 w = gl_root(log_n), sh = shift ? shift : 1;
+        for (u32 par = 0; rc == ZK_OK && par < (1u << r); par++) {
+            TwoLevel pre = zk_scale_table(ctx, gl_mul(sh, gl_pow(w, par)), 1, ks);
+            rc = zk_ntt_dif(ctx, (const u64 *)d_data, n, tmp + (size_t)bitrev_u32(par, r) * ns, n, ks, n_cols, 0, &pre, 0, 1);
+        }
+        if (rc == ZK_OK) rc = zk_bitrev_copy(ctx, tmp, n, (u64 *)d_data, n, log_n, n_cols);
+    } else if (!inverse) {
         TwoLevel pre; bool has = shift > 1;
         if (has) pre = zk_scale_table(ctx, shift, 1, log_n);
         rc = zk_ntt_dif(ctx, (const u64 *)d_data, n, tmp, n, log_n, n_cols, 0, has ? &pre : nullptr, 0, 1);
@@ -357,16 +378,22 @@ extern "C" int32_t zk_ntt_batch_dev(zk_ctx *ctx, uint64_t *d_data, uint32_t log_
     ctx->release(tmp);
     return rc;
 }
+extern "C" int32_t zk_ntt_batch_dev(zk_ctx *ctx, uint64_t *d_data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift) {
+    return zk_ntt_batch_opts_dev(ctx, d_data, log_n, n_cols, inverse, shift, 0);
+}
 
-extern "C" int32_t zk_ntt_batch(zk_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift) {
-    if (!ctx || !data || log_n > 30 || n_cols == 0) return ZK_ERR_INVALID_ARG;
+extern "C" int32_t zk_ntt_batch_opts(zk_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift, uint32_t zero_factor) {
+    if (!ctx || !data || log_n > 30 || n_cols == 0 || zero_factor > log_n) return ZK_ERR_INVALID_ARG;
     hipSetDevice(ctx->device);
     size_t bytes = ((size_t)n_cols << log_n) * sizeof(u64);
     u64 *d = (u64 *)ctx->alloc(bytes);
     if (!d) return ZK_ERR_OOM;
     int32_t rc = zk_dev_upload(ctx, d, data, bytes);
-    if (rc == ZK_OK) rc = zk_ntt_batch_dev(ctx, d, log_n, n_cols, inverse, shift);
+    if (rc == ZK_OK) rc = zk_ntt_batch_opts_dev(ctx, d, log_n, n_cols, inverse, shift, zero_factor);
     if (rc == ZK_OK) rc = zk_dev_download(ctx, data, d, bytes);
     ctx->release(d);
     return rc;
+}
+extern "C" int32_t zk_ntt_batch(zk_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift) {
+    return zk_ntt_batch_opts(ctx, data, log_n, n_cols, inverse, shift, 0);
 }

@@ -1,5 +1,6 @@
 // Internal interfaces between the prover translation units (prover_*.hip).
 #pragma once
+#include <vector>
 #include "zk_internal.h"
 #include "transcript.h"
 
@@ -43,6 +44,25 @@ int32_t zk_fri_proof_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
 struct FriBatchDesc { u64 point[2]; u32 n_polys; const zk_fri_poly *polys; const u64 *d_point = nullptr; };
 int32_t zk_fri_prove_instance_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger *ch, const zk_batch *const *oracles, u32 n_oracles,
                                   const FriBatchDesc *batches, u32 n_batches, u64 *d_proof, const FriLayout &lay);
+
+// prover_plonk.hip / prover_quotient_jit.hip: parameters of the Plonk vanishing-polynomial kernel (interpreter and compiled gate programs)
+struct PlkQuotParams {
+    const u64 *w_lde, *z_lde, *cs_lde;     // column-major over L, leaf order
+    const u64 *l0;                         // L_0 on the coset, leaf order
+    const u64 *xA, *xB;                    // x_i = g w_L^i
+    const u64 *kis, *bg;
+    const u64 *apow;                       // [challenge][term]: alpha_j^t for every term t of the vanishing polynomial
+    const zk_instr *instrs; const u64 *gconst;
+    const u64 *pih;                        // public_inputs_hash (4 words): the PUBLIC operand of the gate program (PublicInputGate)
+    u64 zh_inv[8];
+    size_t L; u32 lgL, W, NC, R, NZ, qdf, nchunks, nch, n_instrs, n_regs, NT;
+    u64 *out;                              // [challenge][leaf position]
+    u64 *state;                            // compiled gate programs cut into several kernels: [slot][leaf position] between them
+};
+// the gate program of a circuit compiled to gfx950 code (build-time kernel, prover-state file, or hiprtc now); *fn_out == nullptr:
+// none available (small program, ZK_PLONK_JIT=0) -> the interpreter.  is_module: launch with hipModuleLaunchKernel, else hipLaunchKernel
+// (a long program is a SEQUENCE of kernels launched back to back; n_state = u64 slots per coset point of the state buffer between them)
+int32_t zk_plonk_gates_kernel(zk_ctx *ctx, const zk_air *gates, u32 W, u32 NC, u32 nch, u32 rate_bits, std::vector<const void *> &fns, int *is_module, u32 *n_state);
 
 // FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) (plonky2 0.2.2 fri/reduction_strategies.rs):
 //   while degree_bits > final_poly_bits && degree_bits + rate_bits - arity_bits >= cap_height { push; assert!(degree_bits >= arity_bits); .. }

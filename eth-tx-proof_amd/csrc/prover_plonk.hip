@@ -33,6 +33,7 @@ struct zk_plonk_state {
     zk_instr *d_instrs; u64 *d_gconst; u64 *d_kis; u64 *d_digest;
     u32 n_instrs, n_regs, n_gconst, n_gate_terms;
     u64 digest[4];
+    std::vector<const void *> gates_fns; int gates_fn_is_module = 0; u32 gates_n_state = 0;     // the gate program compiled to gfx950 code (zk_plonk_gates_kernel), or none
 };
 
 // number of gate constraint terms (zkgl.h): ZK_OP_EMIT writes term (number of EMITs before it), ZK_OP_EMIT_SLOT term `dst`
@@ -220,18 +221,6 @@ __global__ __launch_bounds__(256) void plonk_partial_products_kernel(const u64 *
     for (u32 c = 0; c < npp; c++) zpp[((size_t)nch + (size_t)ci * npp + c) * n + r] = gl_mul(z, q[((size_t)ci * nchunks + c) * n + r]);
 }
 
-struct PlkQuotParams {
-    const u64 *w_lde, *z_lde, *cs_lde;     // column-major over L, leaf order
-    const u64 *l0;                         // L_0 on the coset, leaf order
-    const u64 *xA, *xB;                    // x_i = g w_L^i
-    const u64 *kis, *bg;
-    const u64 *apow;                       // [challenge][term]: alpha_j^t for every term t of the vanishing polynomial
-    const zk_instr *instrs; const u64 *gconst;
-    const u64 *pih;                        // public_inputs_hash (4 words): the PUBLIC operand of the gate program (PublicInputGate)
-    u64 zh_inv[8];
-    size_t L; u32 lgL, W, NC, R, NZ, qdf, nchunks, nch, n_instrs, n_regs, NT;
-    u64 *out;                              // [challenge][leaf position]
-};
 // alpha_j^t for t < NT (reduce_with_powers): thread = (challenge, t)
 __global__ void plonk_alpha_pows_kernel(const u64 *alphas, u32 nch, u32 NT, u64 *out) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -371,6 +360,7 @@ extern "C" int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const
             if (rc == ZK_OK) rc = zk_dev_download(ctx, st->digest, st->d_digest, 4 * sizeof(u64));
         }
     }
+    if (rc == ZK_OK) rc = zk_plonk_gates_kernel(ctx, c->gates, c->num_wires, NC, cfg->num_challenges, cfg->rate_bits, st->gates_fns, &st->gates_fn_is_module, &st->gates_n_state);
     if (rc != ZK_OK) { zk_plonk_state_free(st); return rc; }
     *out = st;
     return ZK_OK;
@@ -510,10 +500,27 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
             for (u32 i = 0; i < qdf; i++) qp.zh_inv[i] = gl_inv(gl_sub(gl_mul(gn, gl_pow(wr, i)), 1));
             qp.L = L; qp.lgL = lgL; qp.W = W; qp.NC = NC; qp.R = R; qp.NZ = NZ; qp.qdf = qdf; qp.nchunks = nchunks; qp.nch = nch;
             qp.n_instrs = st->n_instrs; qp.n_regs = st->n_regs; qp.out = d_qv; qp.pih = d_pih;
-            ZK_LAUNCH(ctx, "plonk_quotient", plonk_quotient_kernel, g1(L), dim3(256), (size_t)st->n_regs * 256 * sizeof(u64), qp);
+            if (!st->gates_fns.empty()) {     // the circuit's gate program as compiled code (same results as the interpreter kernel below)
+                if (st->gates_n_state) {
+                    qp.state = (u64 *)A_((size_t)st->gates_n_state * L * sizeof(u64));
+                    if (!qp.state) { ctx->release(d_qv); return ctx->fail(ZK_ERR_OOM, "prove_plonk: out of device memory"); }
+                }
+                void *args[] = {&qp};
+                for (size_t kk = 0; kk < st->gates_fns.size() && rc == ZK_OK; kk++) {
+                    hipError_t e;
+                    ProfScope ps(ctx, "plonk_quotient");
+                    if (ctx->sync_launch) fprintf(stderr, "[zk %p] plonk_quotient (compiled gate program, %s, kernel %zu of %zu) grid %u\n", (void *)ctx,
+                                                  st->gates_fn_is_module ? "hiprtc" : "build-time", kk + 1, st->gates_fns.size(), (unsigned)((L + 255) / 256));
+                    if (st->gates_fn_is_module) e = hipModuleLaunchKernel((hipFunction_t)st->gates_fns[kk], (unsigned)((L + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+                    else e = hipLaunchKernel(st->gates_fns[kk], g1(L), dim3(256), args, 0, ctx->stream);
+                    if (e != hipSuccess) rc = ctx->fail(ZK_ERR_HIP, "plonk quotient: launch of a compiled gate kernel failed");
+                    if (ctx->sync_launch) hipStreamSynchronize(ctx->stream);
+                }
+            } else
+                ZK_LAUNCH(ctx, "plonk_quotient", plonk_quotient_kernel, g1(L), dim3(256), (size_t)st->n_regs * 256 * sizeof(u64), qp);
             // coset_ifft(g): leaf-order values -> natural-order coefficients, scaled by L^-1 g^-j; in place
             TwoLevel post = zk_scale_table(ctx, gl_inv(GL_GEN), gl_inv((u64)L % GL_P), lgL);
-            rc = zk_ntt_dit(ctx, d_qv, L, d_qv, L, lgL, nch, 1, nullptr, &post, 0, nullptr, 0);
+            if (rc == ZK_OK) rc = zk_ntt_dit(ctx, d_qv, L, d_qv, L, lgL, nch, 1, nullptr, &post, 0, nullptr, 0);
         }
         // each challenge's L coefficients are qdf polynomials of n coefficients, back to back
         if (rc == ZK_OK) rc = zk_batch_commit_dev(ctx, d_qv, k, Q, cfg.rate_bits, cfg.cap_height, 0, &g.qb);

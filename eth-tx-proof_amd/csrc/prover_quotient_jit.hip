@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -194,6 +195,183 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, co
     s += "}\n";
     return s;
 }
+
+// ------------------------------------------------------------------------------------------------ Plonk gate programs
+// The vanishing-polynomial kernel of zk_prove_plonk (prover_plonk.hip: plonk_quotient_kernel) with the circuit's gate program as
+// straight-line code: program registers in VGPRs, constants as immediates, every wire / constant column loaded once per kernel, every
+// emit one multiply-add with alpha^t from the table.  Same field operations on the same canonical values as the interpreter, so the
+// same bits.  hipcc's time grows with the square of a straight-line function's length, so a long program (the recursion gate set of
+// gates.py: 5 816 instructions) becomes a SEQUENCE of kernels of at most PLK_SEG instructions, launched back to back: kernel k hands
+// the accumulators and the program registers that are still alive at its cut (liveness analysis; cuts are moved to where few are --
+// between two gates none) to kernel k+1 through a per-proof state buffer [slot][point] in HBM.  No calls, no stack.
+// (Two single-kernel forms were tried first.  Chunks as non-inlined device functions taking registers and accumulators through
+// pointers, as the tables' chunked constraint kernels do: the callees hoisted every column load, ran to ~250 VGPRs and ~100 SGPRs, and
+// the kernel ended in a GPU memory fault on its first launch although the same source, run on the host, is exact and in bounds.  Chunks
+// as cases of a switch inside a loop: eight minutes of hipcc and then "illegal VGPR to SGPR copy" for the sticky word of glx<false>.)
+static const char PLK_PARAMS_SRC[] =
+    "struct zk_instr_ { u32 op, dst, a, b; };\n"
+    "struct PlkQuotParams { const u64 *w_lde, *z_lde, *cs_lde; const u64 *l0; const u64 *xA, *xB; const u64 *kis, *bg; const u64 *apow; const zk_instr_ *instrs; const u64 *gconst; "
+    "const u64 *pih; u64 zh_inv[8]; u64 L; u32 lgL, W, NC, R, NZ, qdf, nchunks, nch, n_instrs, n_regs, NT; u64 *out; u64 *state; };\n";
+#define PLK_SEG 768u
+#define PLK_SEG_SLACK 192u
+#define PLK_FENCE 64u
+#define PLK_GEN_VERSION 6u
+
+// where the program is cut and which registers cross each cut
+struct PlkPlan { std::vector<u32> cut; std::vector<std::vector<u32>> live; u32 max_live = 0; };   // segment k = [cut[k], cut[k+1]); live[k]: registers alive at cut[k+1]
+static PlkPlan plonk_plan(const zk_air *air) {
+    const u32 n = air->n_instrs, NR = air->n_regs ? air->n_regs : 1;
+    // live_before[pc]: registers read at or after pc before being written (backward scan)
+    std::vector<std::vector<char>> lb(n + 1, std::vector<char>(NR, 0));
+    for (u32 pc = n; pc-- > 0;) {
+        lb[pc] = lb[pc + 1];
+        const zk_instr &in = air->instrs[pc];
+        if (in.op <= ZK_OP_MUL) lb[pc][in.dst & 0xFFFFFF] = 0;
+        const u32 ops[2] = {in.a, in.b};
+        for (int q = 0; q < (in.op <= ZK_OP_MUL ? 2 : 1); q++) if ((ops[q] >> 24) == ZK_OPND_REG) lb[pc][ops[q] & 0xFFFFFF] = 1;
+    }
+    auto count = [&](u32 pc) { u32 c = 0; for (char b : lb[pc]) c += b; return c; };
+    PlkPlan pl;
+    pl.cut.push_back(0);
+    while (n - pl.cut.back() > PLK_SEG) {
+        const u32 hi = pl.cut.back() + PLK_SEG, lo = hi - PLK_SEG_SLACK;
+        u32 best = hi;
+        for (u32 pc = hi; pc >= lo; pc--) if (count(pc) < count(best)) best = pc;       // the latest cut with the fewest live registers
+        pl.cut.push_back(best);
+    }
+    pl.cut.push_back(n);
+    for (size_t k = 0; k + 1 < pl.cut.size(); k++) {
+        std::vector<u32> lv;
+        if (k + 2 < pl.cut.size()) for (u32 r = 0; r < NR; r++) if (lb[pl.cut[k + 1]][r]) lv.push_back(r);
+        if (lv.size() > pl.max_live) pl.max_live = (u32)lv.size();
+        pl.live.push_back(lv);
+    }
+    return pl;
+}
+
+struct PGen {
+    const zk_air *air; u32 W;
+    std::string body;
+    std::vector<char> have_l, have_pub;
+    std::string opnd(u32 o) {
+        u32 kind = o >> 24, idx = o & 0xFFFFFF;
+        char name[64];
+        switch (kind) {
+        case ZK_OPND_REG: snprintf(name, sizeof name, "r%u", idx); return name;
+        case ZK_OPND_LOCAL:
+            snprintf(name, sizeof name, "l%u", idx);
+            if (!have_l[idx]) {
+                have_l[idx] = 1;
+                if (idx < W) appendf(body, "    const u64 %s = wp[%uull * Lq];\n", name, idx);
+                else appendf(body, "    const u64 %s = cp[%uull * Lq];\n", name, idx - W);
+            }
+            return name;
+        case ZK_OPND_CONST: {
+            // small constants as immediates; full-width ones from the program's constant table in HBM (scalar loads, canonical since
+            // zk_plonk_setup): as immediates, hipcc's constant hoisting parks hundreds of 64-bit literals in registers from the kernel's start
+            const u64 v = gl_canon(air->constants[idx]);
+            if (v < (1ull << 16)) snprintf(name, sizeof name, "0x%llxull", (unsigned long long)v);
+            else snprintf(name, sizeof name, "gc[%u]", idx);
+            return name;
+        }
+        default:
+            snprintf(name, sizeof name, "pub%u", idx);
+            if (!have_pub[idx]) { have_pub[idx] = 1; appendf(body, "    const u64 %s = p.pih[%u];\n", name, idx); }
+            return name;
+        }
+    }
+};
+
+// kernels kname_0 .. kname_{K-1}; *n_kernels, *n_state (state slots per point: nch accumulators + the most registers alive at a cut)
+static std::string generate_plonk(const zk_air *air, u32 W, u32 NC, u32 nch, u32 rate_bits, const char *kname, bool standalone, u32 *n_kernels, u32 *n_state) {
+    std::string s;
+    if (standalone) { s += "#include \"gl64.cuh\"\n"; s += PLK_PARAMS_SRC; }
+    const u32 NR = air->n_regs ? air->n_regs : 1;
+    const PlkPlan pl = plonk_plan(air);
+    const u32 K = (u32)pl.live.size();
+    if (n_kernels) *n_kernels = K + 1;
+    if (n_state) *n_state = nch + pl.max_live;
+    // kernel 0: the permutation part [L_0 (Z - 1)] [partial-product checks] -- the loop code of the interpreter kernel, with its
+    // arithmetic (canonical gl_mul: no sticky word carried around loops), accumulators to the state buffer
+    appendf(s, "extern \"C\" __global__ __launch_bounds__(256) void %s_0(PlkQuotParams p) {\n", kname);
+    s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
+    s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n    const u64 sn = bitrev_u32((i + p.qdf) & (u32)(p.L - 1), p.lgL);\n";
+    s += "    const u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = 0;\n", j);
+    s += "    const u32 npp = p.nchunks - 1;\n    const u64 l0v = p.l0[s];\n    u32 ti = 0;\n";
+    s += "    for (u32 ci = 0; ci < p.nch; ci++, ti++) { const u64 t = gl_mul(l0v, gl_sub(p.z_lde[(u64)ci * p.L + s], 1));\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "        acc%u = gl_mul_add(t, p.apow[%uull * p.NT + ti], acc%u);\n", j, j, j);
+    s += "    }\n";
+    s += "    for (u32 ci = 0; ci < p.nch; ci++) {\n        const u64 beta = p.bg[ci], gamma = p.bg[p.nch + ci];\n        for (u32 c = 0; c < p.nchunks; c++, ti++) {\n";
+    s += "            u64 num = 1, den = 1;\n            for (u32 u = 0; u < p.qdf; u++) {\n                const u32 j = c * p.qdf + u;\n                const u64 w = p.w_lde[(u64)j * p.L + s];\n";
+    s += "                num = gl_mul(num, gl_add(gl_add(w, gl_mul(beta, gl_mul(p.kis[j], x))), gamma));\n";
+    s += "                den = gl_mul(den, gl_add(gl_add(w, gl_mul(beta, p.cs_lde[(u64)(p.NC + j) * p.L + s])), gamma));\n            }\n";
+    s += "            const u64 prev = c == 0 ? p.z_lde[(u64)ci * p.L + s] : p.z_lde[((u64)p.nch + (u64)ci * npp + c - 1) * p.L + s];\n";
+    s += "            const u64 next = c == p.nchunks - 1 ? p.z_lde[(u64)ci * p.L + sn] : p.z_lde[((u64)p.nch + (u64)ci * npp + c) * p.L + s];\n";
+    s += "            const u64 t = gl_sub(gl_mul(prev, num), gl_mul(next, den));\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "            acc%u = gl_mul_add(t, p.apow[%uull * p.NT + ti], acc%u);\n", j, j, j);
+    s += "        }\n    }\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "    p.state[%uull * p.L + s] = acc%u;\n", j, j);
+    s += "}\n";
+    u32 seq = 0;
+    for (u32 k = 0; k < K; k++) {
+        PGen g; g.air = air; g.W = W;
+        g.have_l.assign(W + NC, 0); g.have_pub.assign(4, 0);
+        for (u32 pc = pl.cut[k]; pc < pl.cut[k + 1]; pc++) {
+            const zk_instr &in = air->instrs[pc];
+            // every PLK_FENCE instructions the column base pointers pass through an empty asm: loads behind it cannot be hoisted above it.
+            // Left alone, hipcc hoists every column load of a kernel to its top, runs to 512 registers (VGPRs + AGPRs) and still spills to
+            // scratch; a gate kernel with scratch on several streams at once ended in a GPU memory fault.
+            // ... and a branch the compiler cannot decide (never taken: n_regs is a small number) ends the basic block there, so that the
+            // scheduler does not pull the materialisation of hundreds of 64-bit constants (PoseidonGate's partial rounds) to the top either.
+            if (pc > pl.cut[k] && (pc - pl.cut[k]) % PLK_FENCE == 0)
+                appendf(g.body, "    asm volatile(\"\" : \"+v\"(wp), \"+v\"(cp), \"+s\"(gc));\n    if (p.n_regs == 0x7FFF0000u + %uu) return;\n", pc);
+            std::string a = g.opnd(in.a);
+            if (in.op <= ZK_OP_MUL) {
+                std::string b = g.opnd(in.b);
+                appendf(g.body, "    r%u = %s(%s, %s);\n", in.dst & 0xFFFFFF, in.op == ZK_OP_ADD ? "gl_add" : in.op == ZK_OP_SUB ? "gl_sub" : "g.mul", a.c_str(), b.c_str());
+            } else {
+                const u32 slot = in.op == ZK_OP_EMIT ? seq++ : in.dst;
+                g.body += "    {";
+                for (u32 j = 0; j < nch; j++) appendf(g.body, " acc%u = g.mul_add(%s, ap%u[%u], acc%u);", j, a.c_str(), j, slot, j);
+                g.body += " }\n";
+            }
+        }
+        appendf(s, "extern \"C\" __global__ __launch_bounds__(256) void %s_%u(PlkQuotParams p) {\n", kname, k + 1);
+        s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
+        s += "    const u32 gbase = p.nch + p.nch * p.nchunks;\n";
+        for (u32 j = 0; j < nch; j++) appendf(s, "    const u64 *ap%u = p.apow + %uull * p.NT + gbase;\n", j, j);
+        // what the previous kernel left: read before anything is written (the exact redo starts from the same values)
+        for (u32 j = 0; j < nch; j++) appendf(s, "    const u64 in_acc%u = p.state[%uull * p.L + s];\n", j, j);
+        if (k > 0) for (size_t q = 0; q < pl.live[k - 1].size(); q++) appendf(s, "    const u64 in_r%u = p.state[%uull * p.L + s];\n", pl.live[k - 1][q], (u32)(nch + q));
+        s += "    auto eval = [&](auto &g) {\n";
+        s += "    const u64 *wp = p.w_lde + s, *cp = p.cs_lde + s, *gc = p.gconst;\n    const u64 Lq = p.L;\n";
+        {
+            for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = in_acc%u;\n", j, j);
+            for (u32 r = 0; r < NR; r++) {
+                bool lv = false;
+                if (k > 0) for (u32 q : pl.live[k - 1]) lv |= q == r;
+                if (lv) appendf(s, "    u64 r%u = in_r%u;\n", r, r); else appendf(s, "    u64 r%u = 0;\n", r);
+            }
+        }
+        s += g.body;
+        if (k + 1 < K) {
+            for (u32 j = 0; j < nch; j++) appendf(s, "    p.state[%uull * p.L + s] = acc%u;\n", j, j);
+            for (size_t q = 0; q < pl.live[k].size(); q++) appendf(s, "    p.state[%uull * p.L + s] = r%u;\n", (u32)(nch + q), pl.live[k][q]);
+        } else {
+            s += "    const u32 i2 = bitrev_u32((u32)s, p.lgL);\n    u64 zi = p.zh_inv[0];\n";
+            appendf(s, "    { const u32 zsel = i2 & %uu;\n", (1u << rate_bits) - 1);
+            for (u32 j = 1; j < (1u << rate_bits); j++) appendf(s, "      zi = zsel == %uu ? p.zh_inv[%u] : zi;\n", j, j);
+            s += "    }\n";
+            for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = g.mul(acc%u, zi);\n", j, j);
+        }
+        s += "    };\n";
+        s += "    glx<false> gf; gf.fl = 0;\n    eval(gf);\n";
+        s += "    if (gf.fl != 0) { glx<true> ge; ge.fl = 0; eval(ge); }\n";
+        s += "}\n";
+    }
+    return s;
+}
 }  // namespace
 
 // everything the generated source depends on, verbatim (the cache key of compiled kernels; its FNV-1a hash names ahead-of-time ones)
@@ -339,25 +517,36 @@ extern "C" int32_t zk_prover_state_stats(uint64_t *compiled, uint64_t *loaded_fr
     return ZK_OK;
 }
 
-static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k) {
-    std::string key = air_key(air, C, A, nch, rate_bits);
+// The code object of one generated kernel: process cache -> prover-state file -> hiprtc.  `key`: everything the source depends on;
+// the file's key adds the generator version, the field header, the GPU architecture and the hiprtc version, so a library, driver or
+// hardware change never loads a stale image; an image that fails to load is deleted and rebuilt.  settle_args: a zeroed parameter block
+// (L = 0: every thread returns at once) for the first launch of the freshly loaded code object.
+static int32_t jit_compile_cached(zk_ctx *ctx, const std::string &base_key, bool may_compile, const std::function<std::string()> &gen, const char *kname,
+                                  void *settle_args, JitKernel &k) {
+    std::string key = base_key;
     { u32 dev = (u32)ctx->device; key.append((const char *)&dev, sizeof dev); }
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) { k = it->second; return ZK_OK; }
+    if (!may_compile) { k = JitKernel(); return ZK_OK; }
+    std::string disk_key = base_key;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_cache.find(key);
-        if (it == g_cache.end()) {
-            if (!may_compile) { k = JitKernel(); return ZK_OK; }
-            // device-independent (the code object is per architecture); tied to the generator and to the field header it compiles
-            // against, so a library upgrade never runs a stale kernel
-            std::string disk_key = air_key(air, C, A, nch, rate_bits);
-            { const u64 ver[2] = {3 /* generator version */, fnv1a(GL64_SRC)}; disk_key.append((const char *)ver, sizeof ver); }
-            k.image = std::make_shared<std::vector<char>>();
-            const bool from_disk = co_load(disk_key, *k.image);
-            std::string src = from_disk ? std::string() : generate(air, C, A, nch, rate_bits);
-            if (!from_disk) if (const char *dump = getenv("ZK_QUOTIENT_JIT_DUMP")) {       // debugging aid: the generated source, for offline inspection
+        const u64 ver[2] = {4 /* generator version */, fnv1a(GL64_SRC)};
+        disk_key.append((const char *)ver, sizeof ver);
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) disk_key.append(pr.gcnArchName);
+        int rmaj = 0, rmin = 0;
+        if (hiprtcVersion(&rmaj, &rmin) == HIPRTC_SUCCESS) { const int rv[2] = {rmaj, rmin}; disk_key.append((const char *)rv, sizeof rv); }
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        k = JitKernel();
+        k.image = std::make_shared<std::vector<char>>();
+        const bool from_disk = attempt == 0 && co_load(disk_key, *k.image);
+        if (!from_disk) {
+            std::string src = gen();
+            if (const char *dump = getenv("ZK_QUOTIENT_JIT_DUMP")) {       // debugging aid: the generated source, for offline inspection
                 if (FILE *f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
             }
-            if (!from_disk) {
             hiprtcProgram prog;
             const char *hs[] = {GL64_SRC}, *hn[] = {"gl64.cuh"};
             if (hiprtcCreateProgram(&prog, src.c_str(), "quotient_jit.hip", 1, hs, hn) != HIPRTC_SUCCESS)
@@ -376,27 +565,103 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
             hiprtcDestroyProgram(&prog);
             co_store(disk_key, *k.image);
             g_n_compiled++;
-            } else g_n_loaded++;
-            std::vector<char> &code = *k.image;
-            if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: hipModuleLoadData failed");
-            if (hipModuleGetFunction(&k.fn, k.mod, "quotient_jit") != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: kernel not found in module");
-            // Round 1 refused generated kernels that spill to scratch (faults were seen with such kernels on several streams).  Round 2's
-            // fault hunt ran a scratch-resident kernel between the real kernels of 2400 proofs on 8 streams without a fault
-            // (profiles/r02g_stress_faults.jsonl), so spilling kernels are used; ZK_QUOTIENT_JIT_NO_SCRATCH=1 refuses them again.
-            static const bool no_scratch = getenv("ZK_QUOTIENT_JIT_NO_SCRATCH") && atoi(getenv("ZK_QUOTIENT_JIT_NO_SCRATCH"));
-            int scratch = 0;
-            if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.fn) != hipSuccess || (no_scratch && scratch > 0)) k.fn = nullptr;
-            if (k.fn) {
-                // settle the freshly loaded code object before it is used in earnest: drain the stream, run the kernel once
-                // with L = 0 (every thread returns at its first instruction) and wait for it
-                QJitParams z = {};
-                void *zargs[] = {&z};
-                if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipModuleLaunchKernel(k.fn, 1, 1, 1, 256, 1, 1, 0, ctx->stream, zargs, nullptr) != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess)
-                    k.fn = nullptr;
+        }
+        std::vector<char> &code = *k.image;
+        if (hipModuleLoadData(&k.mod, code.data()) != hipSuccess || hipModuleGetFunction(&k.fn, k.mod, kname) != hipSuccess) {
+            if (from_disk) {        // a stale or foreign image behind a matching key: drop the file, build from source
+                fprintf(stderr, "[zkgl] prover state file %s does not load on this device, rebuilding\n", co_path(disk_key).c_str());
+                remove(co_path(disk_key).c_str());
+                continue;
             }
-            g_cache.emplace(key, k);
-        } else k = it->second;
+            return ctx->fail(ZK_ERR_HIP, "quotient jit: the compiled code object does not load");
+        }
+        if (from_disk) g_n_loaded++;
+        break;
     }
+    // Round 1 refused generated kernels that spill to scratch (faults were seen with such kernels on several streams).  Round 2's
+    // fault hunt ran a scratch-resident kernel between the real kernels of 2400 proofs on 8 streams without a fault
+    // (profiles/r02g_stress_faults.jsonl), so spilling kernels are used; ZK_QUOTIENT_JIT_NO_SCRATCH=1 refuses them again.
+    static const bool no_scratch = getenv("ZK_QUOTIENT_JIT_NO_SCRATCH") && atoi(getenv("ZK_QUOTIENT_JIT_NO_SCRATCH"));
+    int scratch = 0;
+    if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.fn) != hipSuccess || (no_scratch && scratch > 0)) k.fn = nullptr;
+    if (k.fn) {
+        // settle the freshly loaded code object before it is used in earnest: drain the stream, run the kernel once
+        // with L = 0 (every thread returns at its first instruction) and wait for it
+        void *zargs[] = {settle_args};
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipModuleLaunchKernel(k.fn, 1, 1, 1, 256, 1, 1, 0, ctx->stream, zargs, nullptr) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            k.fn = nullptr;
+    }
+    g_cache.emplace(key, k);
+    return ZK_OK;
+}
+
+static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k) {
+    QJitParams z = {};
+    return jit_compile_cached(ctx, air_key(air, C, A, nch, rate_bits), may_compile, [&]() { return generate(air, C, A, nch, rate_bits); }, "quotient_jit", &z, k);
+}
+
+// ---- Plonk gate programs: build-time registry (prover_plonk_aot.hip, tools/gen_aot_quotient.py), else hiprtc at zk_plonk_setup
+struct PlkAotEntry { const void *const *fns; u32 n_kernels, n_state; };
+const PlkAotEntry *zk_plonk_gates_aot_lookup(u64 key_hash);
+static std::string plonk_key(const zk_air *g, u32 W, u32 NC, u32 nch, u32 rate_bits) {
+    std::string key = "PLONK";
+    u32 hdr[11] = {W, NC, nch, rate_bits, g->n_regs, g->n_instrs, g->n_constants, PLK_SEG, PLK_SEG_SLACK, PLK_FENCE, PLK_GEN_VERSION};
+    key.append((const char *)hdr, sizeof hdr);
+    key.append((const char *)g->instrs, (size_t)g->n_instrs * sizeof(zk_instr));
+    key.append((const char *)g->constants, (size_t)g->n_constants * sizeof(u64));
+    return key;
+}
+// ZK_PLONK_JIT: 0 = interpreter always; 1 (default) = build-time kernels, and hiprtc for programs of at least 256 instructions;
+// 2 = hiprtc for every program that has no build-time kernel
+int32_t zk_plonk_gates_kernel(zk_ctx *ctx, const zk_air *gates, u32 W, u32 NC, u32 nch, u32 rate_bits, std::vector<const void *> &fns, int *is_module, u32 *n_state) {
+    fns.clear(); *is_module = 0; *n_state = 0;
+    static const int mode = getenv("ZK_PLONK_JIT") ? atoi(getenv("ZK_PLONK_JIT")) : 1;
+    if (mode <= 0 || gates->n_instrs == 0) return ZK_OK;
+    const std::string key = plonk_key(gates, W, NC, nch, rate_bits);
+    if (ctx->quotient_aot)
+        if (const PlkAotEntry *e = zk_plonk_gates_aot_lookup(fnv1a(key))) { fns.assign(e->fns, e->fns + e->n_kernels); *n_state = e->n_state; return ZK_OK; }
+    if (mode == 1 && gates->n_instrs < 256) return ZK_OK;
+    u32 K = 0, ns = 0;
+    (void)generate_plonk(gates, W, NC, nch, rate_bits, "plonk_gates_jit", true, &K, &ns);       // the plan (cheap next to the compile)
+    JitKernel k0;
+    PlkQuotParams z = {};
+    int32_t rc = jit_compile_cached(ctx, key, true, [&]() { return generate_plonk(gates, W, NC, nch, rate_bits, "plonk_gates_jit", true, nullptr, nullptr); },
+                                    "plonk_gates_jit_0", &z, k0);
+    if (rc != ZK_OK) return rc;
+    if (!k0.fn) return ZK_OK;
+    fns.push_back((const void *)k0.fn);
+    for (u32 k = 1; k < K; k++) {
+        char nm[64]; snprintf(nm, sizeof nm, "plonk_gates_jit_%u", k);
+        hipFunction_t f = nullptr;
+        if (hipModuleGetFunction(&f, k0.mod, nm) != hipSuccess) { fns.clear(); return ctx->fail(ZK_ERR_HIP, "plonk gate kernels: a kernel of the sequence is missing from the module"); }
+        fns.push_back((const void *)f);
+    }
+    *is_module = 1; *n_state = ns;
+    return ZK_OK;
+}
+// The source of the gate kernels of one program, for the build-time generator (host only).  W / NC: wires / constant columns of the circuit.
+extern "C" int32_t zk_plonk_gates_kernel_source(const zk_air *gates, uint32_t num_wires, uint32_t num_constants, uint32_t num_challenges, uint32_t rate_bits,
+                                                char *buf, size_t cap, size_t *len, uint64_t *key_hash, uint32_t *n_kernels, uint32_t *n_state) {
+    if (!gates || !len || !key_hash || (gates->n_instrs && !gates->instrs) || (gates->n_constants && !gates->constants)) return ZK_ERR_INVALID_ARG;
+    for (u32 pc = 0; pc < gates->n_instrs; pc++) {       // the generator indexes by operand
+        const zk_instr &in = gates->instrs[pc];
+        if (in.op > ZK_OP_EMIT && in.op != ZK_OP_EMIT_SLOT) return ZK_ERR_INVALID_ARG;
+        const u32 ops[2] = {in.a, in.b};
+        for (int q = 0; q < (in.op <= ZK_OP_MUL ? 2 : 1); q++) {
+            const u32 kd = ops[q] >> 24, ix = ops[q] & 0xFFFFFFu;
+            if (!(kd == ZK_OPND_REG ? ix < gates->n_regs : kd == ZK_OPND_LOCAL ? ix < num_wires + num_constants : kd == ZK_OPND_CONST ? ix < gates->n_constants : kd == ZK_OPND_PUBLIC ? ix < 4 : false))
+                return ZK_ERR_INVALID_ARG;
+        }
+        if (in.op <= ZK_OP_MUL && (in.dst & 0xFFFFFFu) >= gates->n_regs) return ZK_ERR_INVALID_ARG;
+    }
+    const u64 h = fnv1a(plonk_key(gates, num_wires, num_constants, num_challenges, rate_bits));
+    char name[64]; snprintf(name, sizeof name, "plonk_gates_aot_%016llx", (unsigned long long)h);
+    u32 K = 0, ns = 0;
+    std::string src = generate_plonk(gates, num_wires, num_constants, num_challenges, rate_bits, name, false, &K, &ns);
+    *len = src.size(); *key_hash = h;
+    if (n_kernels) *n_kernels = K;
+    if (n_state) *n_state = ns;
+    if (buf) { if (cap < src.size() + 1) return ZK_ERR_BUFFER_TOO_SMALL; memcpy(buf, src.c_str(), src.size() + 1); }
     return ZK_OK;
 }

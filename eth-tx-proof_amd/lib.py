@@ -129,13 +129,14 @@ class Context:
         return out
 
     # ---- field / NTT  (fft_with_options / ifft_with_options / coset_fft / coset_ifft)
-    def ntt(self, cols, inverse=False, shift=0):
+    def ntt(self, cols, inverse=False, shift=0, zero_factor=0):
+        """fft_with_options / ifft_with_options / coset_fft_with_options; zero_factor = r: only the first n >> r inputs count"""
         a = _u64(cols).copy()
         a2 = a.reshape(-1, a.shape[-1])
         log_n = a2.shape[1].bit_length() - 1
         assert 1 << log_n == a2.shape[1]
-        self._chk(lib().zk_ntt_batch(self.h, _p(a2), C.c_uint32(log_n), C.c_uint32(a2.shape[0]),
-                                     C.c_int32(1 if inverse else 0), C.c_uint64(shift)), "zk_ntt_batch")
+        self._chk(lib().zk_ntt_batch_opts(self.h, _p(a2), C.c_uint32(log_n), C.c_uint32(a2.shape[0]),
+                                          C.c_int32(1 if inverse else 0), C.c_uint64(shift), C.c_uint32(zero_factor)), "zk_ntt_batch_opts")
         return a
 
     def ntt_dev(self, dptr, log_n, n_cols, inverse=False, shift=0):

@@ -180,7 +180,7 @@ class SyntheticRecursion:
         self.threshold = (self.THRESHOLD_DEGREE_BITS + size_shift) if threshold is None else threshold
         self.ranges = degree_bits_ranges
         self.fixed_bits = degree_bits
-        self._states, self._lock = {}, threading.Lock()
+        self._states, self._lock, self._pinned = {}, threading.Lock(), {}
 
     # ---- sizes
     def _bits(self, b):
@@ -256,9 +256,26 @@ class SyntheticRecursion:
         st[:pubs.size] = pubs
         return ctx.poseidon(st[None, :])[0][:4]
 
-    def job(self, ctx, kind, pubs, key=0, degree_bits=None):
+    def witness(self, ctx, kind, key, degree_bits, pih):
+        """The circuit's witness for THIS proof: the calling worker's own copy of the stand-in witness in pinned host memory (one
+        asynchronous upload at PCIe rate inside zk_prove_plonk, as for a trace from zk_host_alloc), PublicInputGate cells rewritten
+        in place.  Upstream generates the witness of every proof on the CPU (plonky2::iop::generator) -- not reproduced here."""
+        import threading
+        from . import lib as zl, ops
         circ, wires = self.circuit(kind, key, degree_bits)
-        return self.state(ctx, kind, key, degree_bits), bind_public_inputs(circ, wires, self.public_inputs_hash(ctx, pubs)), pubs
+        k = (threading.get_ident(), ctx.device, kind, key, degree_bits)
+        buf = self._pinned.get(k)
+        if buf is None:
+            owner = ops.P_STATE.state_ctx() if ops.P_STATE is not None and ops.P_STATE.device == ctx.device else ctx
+            buf = zl.pinned_empty(owner, wires.shape)
+            buf[...] = wires
+            self._pinned[k] = buf
+        for i, col in enumerate(circ.pi_wires):
+            buf[col, 0] = np.uint64(int(pih[i]))
+        return buf
+
+    def job(self, ctx, kind, pubs, key=0, degree_bits=None):
+        return self.state(ctx, kind, key, degree_bits), self.witness(ctx, kind, key, degree_bits, self.public_inputs_hash(ctx, pubs)), pubs
 
     # ---- ops.RecursionCircuits
     def shrink_chain(self, table, air, log_n):

@@ -143,3 +143,102 @@ def to_json(proof_words, cfg):
 
 def from_json(text, cfg):
     return from_dict(json.loads(text), cfg)
+
+
+# ------------------------------------------------------------------------------------------------ Plonk proofs (the recursion half)
+# plonky2 0.2.2 plonk::proof (names RECALLED, as above):
+#   ProofWithPublicInputs { proof: Proof, public_inputs: [u64] }
+#   Proof { wires_cap, plonk_zs_partial_products_cap, quotient_polys_cap, openings: OpeningSet, opening_proof: FriProof }
+#   OpeningSet { constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys, lookup_zs, lookup_zs_next }
+# and the reference's own wrappers (proof_gen::proof_types, what `serde_json::to_vec(&proof)` at /root/reference/leader/src/main.rs:60 writes):
+#   GeneratedTxnProof / GeneratedAggProof { p_vals: PublicValues, intern: ProofWithPublicInputs },  GeneratedBlockProof { b_height, intern }
+# The proof words also carry what upstream keeps in CommonCircuitData (degree_bits, wire / constant counts): kept under "common" so
+# that plonk_from_dict is an exact inverse.
+PLONK_MAGIC = 0x314B4C504C474B5A
+
+
+def plonk_to_dict(proof_words, cfg, public_inputs=()):
+    """-> {"common": {..}, "proof_with_pis": ProofWithPublicInputs-shaped dict}; cfg: the recursion config the proof was made with"""
+    r = _R(proof_words)
+    if r.one() != PLONK_MAGIC:
+        raise ValueError("bad magic")
+    k, W, R, NC = r.one(), r.one(), r.one(), r.one()
+    nch, qdf, capw = cfg.num_challenges, 1 << cfg.rate_bits, 4 << cfg.cap_height
+    if R == 0 or R % qdf:
+        raise ValueError("routed wires not a multiple of the quotient degree factor")
+    npp = R // qdf - 1
+    lgL = k + cfg.rate_bits
+    wires_cap, zs_cap, quot_cap = _hashes(r.take(capw)), _hashes(r.take(capw)), _hashes(r.take(capw))
+    o = {"constants": _exts(r.take(2 * NC)), "plonk_sigmas": _exts(r.take(2 * R)), "wires": _exts(r.take(2 * W)),
+         "plonk_zs": _exts(r.take(2 * nch)), "plonk_zs_next": _exts(r.take(2 * nch)), "partial_products": _exts(r.take(2 * nch * npp)),
+         "quotient_polys": _exts(r.take(2 * nch * qdf)), "lookup_zs": [], "lookup_zs_next": []}
+    ar = _arities(cfg, k)
+    if r.one() != len(ar):
+        raise ValueError("unexpected number of FRI layers")
+    caps = [_hashes(r.take(capw)) for _ in ar]
+    flen = r.one()
+    final = _exts(r.take(2 * flen))
+    pow_witness = r.one()
+    npath = lgL - cfg.cap_height
+    rounds = []
+    for _q in range(cfg.num_query_rounds):
+        evals_proofs = []
+        for ncols in (NC + R, W, nch * (1 + npp), nch * qdf):
+            leaf = r.take(ncols)
+            evals_proofs.append([leaf, {"siblings": _hashes(r.take(4 * npath))}])
+        steps, lg = [], lgL
+        for ab in ar:
+            ev = _exts(r.take(2 << ab))
+            lg -= ab
+            steps.append({"evals": ev, "merkle_proof": {"siblings": _hashes(r.take(4 * (lg - cfg.cap_height)))}})
+        rounds.append({"initial_trees_proof": {"evals_proofs": evals_proofs}, "steps": steps})
+    if r.p != len(r.w):
+        raise ValueError("trailing words")
+    return {"common": {"degree_bits": k, "num_wires": W, "num_routed_wires": R, "num_constants": NC},
+            "proof_with_pis": {"proof": {"wires_cap": wires_cap, "plonk_zs_partial_products_cap": zs_cap, "quotient_polys_cap": quot_cap, "openings": o,
+                                         "opening_proof": {"commit_phase_merkle_caps": caps, "query_round_proofs": rounds,
+                                                           "final_poly": {"coeffs": final}, "pow_witness": pow_witness}},
+                               "public_inputs": [int(x) for x in public_inputs]}}
+
+
+def plonk_from_dict(d):
+    """exact inverse of plonk_to_dict: -> (proof words, public inputs)"""
+    c, pw = d["common"], d["proof_with_pis"]
+    p, o = pw["proof"], pw["proof"]["openings"]
+    fh = lambda hs: [x for h in hs for x in h["elements"]]
+    fe = lambda es: [x for e in es for x in e]
+    w = [PLONK_MAGIC, c["degree_bits"], c["num_wires"], c["num_routed_wires"], c["num_constants"]]
+    w += fh(p["wires_cap"]) + fh(p["plonk_zs_partial_products_cap"]) + fh(p["quotient_polys_cap"])
+    for key in ("constants", "plonk_sigmas", "wires", "plonk_zs", "plonk_zs_next", "partial_products", "quotient_polys"):
+        w += fe(o[key])
+    f = p["opening_proof"]
+    w += [len(f["commit_phase_merkle_caps"])]
+    for cap in f["commit_phase_merkle_caps"]:
+        w += fh(cap)
+    w += [len(f["final_poly"]["coeffs"])] + fe(f["final_poly"]["coeffs"]) + [f["pow_witness"]]
+    for q in f["query_round_proofs"]:
+        for leaf, mp in q["initial_trees_proof"]["evals_proofs"]:
+            w += list(leaf) + fh(mp["siblings"])
+        for s in q["steps"]:
+            w += fe(s["evals"]) + fh(s["merkle_proof"]["siblings"])
+    return np.array(w, dtype=np.uint64), np.array(pw["public_inputs"], dtype=np.uint64)
+
+
+def block_proof_to_json(block, cfg, public_inputs):
+    """GeneratedBlockProof { b_height, intern } as the leader prints it (/root/reference/leader/src/main.rs:60)"""
+    d = plonk_to_dict(block.intern, cfg, public_inputs)
+    return json.dumps({"b_height": int(block.b_height), "intern": d["proof_with_pis"], "common": d["common"]}, separators=(",", ":"))
+
+
+def block_proof_from_json(text):
+    """-> (b_height, proof words, public inputs)"""
+    j = json.loads(text)
+    words, pis = plonk_from_dict({"common": j["common"], "proof_with_pis": j["intern"]})
+    return int(j["b_height"]), words, pis
+
+
+def txn_proof_to_json(agg_proof, cfg, public_inputs):
+    """GeneratedTxnProof / GeneratedAggProof { p_vals, intern }: p_vals here = the tables' public inputs the unit carried"""
+    d = plonk_to_dict(agg_proof.proof, cfg, public_inputs)
+    return json.dumps({"p_vals": [[int(x) for x in pv] for pv in agg_proof.public_values], "intern": d["proof_with_pis"], "common": d["common"]},
+                      separators=(",", ":"))

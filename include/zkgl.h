@@ -90,6 +90,12 @@ int32_t zk_trace_upload_async(zk_ctx *ctx, const uint64_t *trace, size_t n_words
  */
 int32_t zk_ntt_batch(zk_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift);
 int32_t zk_ntt_batch_dev(zk_ctx *ctx, uint64_t *d_data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift);
+/* the same with upstream's `zero_factor: Option<usize>` (fft_with_options / ifft_with_options / coset_fft_with_options): zero_factor = r
+ * promises that only the first 2^log_n >> r inputs of every column are non-zero; the rest of the input is TAKEN AS zero (upstream skips
+ * the butterfly layers that would only copy).  r = 0: no promise (None).  The forward transform then runs as 2^r transforms of size
+ * 2^(log_n - r) on cosets instead of one of size 2^log_n.  r > log_n: ZK_ERR_INVALID_ARG. */
+int32_t zk_ntt_batch_opts(zk_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift, uint32_t zero_factor);
+int32_t zk_ntt_batch_opts_dev(zk_ctx *ctx, uint64_t *d_data, uint32_t log_n, uint32_t n_cols, int32_t inverse, uint64_t shift, uint32_t zero_factor);
 
 /* ------------------------------------------------------------------ Poseidon
  * plonky2::hash::poseidon::{Poseidon::poseidon, PoseidonHash::{hash_no_pad, two_to_one}}, hashing::hash_or_noop.
@@ -402,6 +408,15 @@ size_t zk_plonk_proof_size_words(const zk_stark_config *cfg, const zk_plonk_circ
 int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfg, zk_plonk_state *st, const uint64_t *wires, uint32_t wires_on_device,
                        const uint64_t *public_inputs, uint32_t n_public_inputs, uint64_t *proof_out, size_t proof_cap_words,
                        size_t *proof_len_words);
+
+/* Build-time half of the circuits' prover state, as zk_quotient_kernel_source for the tables: the HIP source of the vanishing-polynomial
+ * kernel with this gate program as straight-line code, and the hash that names it.  Host only; tools/gen_aot_quotient.py writes the
+ * kernel of the recursion gate set into csrc/prover_plonk_aot.hip, which is compiled with the library; zk_plonk_setup finds it there,
+ * compiles other programs of >= 256 instructions with hiprtc (kept in the prover-state directory like the tables' kernels) and leaves
+ * small ones to the interpreter kernel (ZK_PLONK_JIT=0: always the interpreter).  A long program comes out as a SEQUENCE of *n_kernels kernels
+ * (<name>_0 ..), launched back to back, that hand *n_state u64 per coset point to each other through a state buffer.  buf may be NULL. */
+int32_t zk_plonk_gates_kernel_source(const zk_air *gates, uint32_t num_wires, uint32_t num_constants, uint32_t num_challenges, uint32_t rate_bits,
+                                     char *buf, size_t cap, size_t *len, uint64_t *key_hash, uint32_t *n_kernels, uint32_t *n_state);
 
 /* Synthetic satisfying witness for eth_tx_proof_amd.air.cpu_like_air, generated in HBM;
  * public_inputs_out (host, 3 words, may be NULL) = first-row a0, b0 and last-row a0. */

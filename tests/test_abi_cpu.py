@@ -91,6 +91,36 @@ def test_build_time_constraint_kernels_are_what_the_generator_emits(zk):
     assert L.zk_quotient_kernel_source(prog.ref, C.c_uint32(2), C.c_uint32(1), small, C.c_size_t(16), C.byref(ln), C.byref(h)) != 0
 
 
+def test_build_time_plonk_gate_kernel_is_what_the_generator_emits(zk):
+    """csrc/prover_plonk_aot.hip holds, verbatim, what zk_plonk_gates_kernel_source emits for the recursion gate set of gates.py (the
+    gate program every stand-in recursion circuit shares): the build-time kernel and a hiprtc-compiled one are the same text."""
+    import os
+    from eth_tx_proof_amd import gates as GT
+    L = zk.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "eth-tx-proof_amd", "csrc", "prover_plonk_aot.hip")).read()
+    prog, groups = GT.gate_program(135)
+    nc = len(groups) + GT.NUM_GATE_CONSTANTS
+    f = L.zk_plonk_gates_kernel_source
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    ln, h, nk, ns = C.c_size_t(0), C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+    assert f(C.cast(prog.ref, C.c_void_p), 135, nc, 2, 3, None, 0, C.byref(ln), C.byref(h), C.byref(nk), C.byref(ns)) == 0
+    buf = C.create_string_buffer(ln.value + 1)
+    assert f(C.cast(prog.ref, C.c_void_p), 135, nc, 2, 3, buf, ln.value + 1, C.byref(ln), C.byref(h), C.byref(nk), C.byref(ns)) == 0
+    src = buf.value.decode()
+    name = "plonk_gates_aot_%016x" % h.value
+    assert src in text and "0x%016xULL" % h.value in text
+    # a sequence of kernels: the permutation part, then the gate program in pieces of at most 768 instructions
+    assert nk.value == 1 + -(-prog.n_instrs // 768) + (1 if prog.n_instrs % 768 > 576 else 0) or nk.value >= 2 + prog.n_instrs // 768
+    assert all("void %s_%d(PlkQuotParams p)" % (name, k) in src for k in range(nk.value)) and "void %s_%d(" % (name, nk.value) not in src
+    assert "%s_fns, %du, %du}" % (name, nk.value, ns.value) in text
+    assert 2 <= ns.value <= 2 + 29                       # two accumulators + the program registers alive at the worst cut
+    assert src.count("g.mul_add(") >= 2 * 2 * 123        # every gate term lands in both challenges' accumulators (fast and exact twin)
+    assert "glx<false>" in src.split("void %s_1(" % name)[1] and "glx" not in src.split("void %s_1(" % name)[0]   # no sticky word around the loops of kernel 0
+    # operands outside the circuit's columns are refused before the generator indexes by them
+    assert f(C.cast(prog.ref, C.c_void_p), 100, nc, 2, 3, None, 0, C.byref(ln), C.byref(h), None, None) == -1
+
+
 def test_air_validate_refuses_malformed_programs(zk):
     """zk_air_validate (host only): a constraint program whose operands index outside its arrays is refused with
     ZK_ERR_INVALID_ARG before it can reach the generator, the interpreter or the helper kernels."""

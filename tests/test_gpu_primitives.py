@@ -65,6 +65,24 @@ def test_ntt_forward_inverse_coset(ctx, orc, log_n):
     assert (ctx.ntt(cf, inverse=True, shift=G) == v % np.uint64(P)).all()
 
 
+@pytest.mark.parametrize("log_n,r", [(4, 1), (6, 3), (10, 1), (12, 2), (14, 3), (16, 1), (5, 5), (3, 0)])
+def test_ntt_zero_factor(ctx, orc, log_n, r):
+    """zk_ntt_batch_opts: upstream's `zero_factor` of fft_with_options / coset_fft_with_options / ifft_with_options -- the transform of
+    the input with everything past the first n >> r entries TAKEN AS zero (whatever the caller left there), equal to the oracle's full
+    transform of the zero-padded input; plain, coset and inverse."""
+    rng = np.random.default_rng(7 * log_n + r)
+    n = 1 << log_n
+    v = field_rand(rng, (3, n))                      # the tail is garbage on purpose: it must be ignored
+    z = v.copy()
+    z[:, n >> r:] = 0
+    assert (ctx.ntt(v, zero_factor=r) == orc.fft(z)).all()
+    assert (ctx.ntt(v, shift=G, zero_factor=r) == orc.fft(z, shift=G)).all()
+    assert (ctx.ntt(v, inverse=True, zero_factor=r) == orc.fft(z, inverse=True)).all()
+    assert (ctx.ntt(z, zero_factor=r) == ctx.ntt(z)).all()
+    with pytest.raises(Exception):
+        ctx.ntt(v, zero_factor=log_n + 1)
+
+
 def test_ntt_golden(ctx):
     g = json.load(open(os.path.join(GOLD, "vectors.json")))
     v = np.array([g["fft_1_to_8"]["input"]], dtype=np.uint64)

@@ -118,6 +118,58 @@ def test_prover_input_map_fold_block(orc):
         ops.P_STATE = old
 
 
+def test_wire_formats_on_gpu_made_proofs(orc):
+    """SURVEY.md 8f-3 on proofs the GPU made: the AllProof (StarkProof per table), a Plonk proof of the chain, the root proof as
+    GeneratedTxnProof and the block proof as the leader prints it (/root/reference/leader/src/main.rs:60) -> serde-shaped JSON -> words:
+    identical words back, the oracle's verifiers accept what was re-read, and reject it after an edit of the JSON."""
+    import json
+    from eth_tx_proof_amd import leader, ops, plonk, wire
+    old = ops.P_STATE
+    ops.P_STATE = None
+    try:
+        rec = plonk.SyntheticRecursion(size_shift=-7, threshold=5, seed=6)
+        st = ops.set_prover_state_from_config(0, recursion=rec)
+        units, unit_items = [], []
+        for u in range(2):
+            tabs, items = _small_tables(orc, 500 + 10 * u, shapes=((9, 7), (12, 6)))
+            units.append(ops.GenerationInputs(tabs, txn_number_before=u, block_number=1))
+            unit_items.append(items)
+        root, pv, all_proof = ops.prove_root(units[0])
+        # ---- StarkProofs
+        back = wire.from_json(wire.to_json(all_proof, st.config), st.config)
+        assert (back == all_proof).all()
+        vitems = [(p, lg, None, pub) for p, lg, _, pub in unit_items[0]]
+        assert orc.verify(st.config, vitems, back) == 0
+        d = wire.to_dict(all_proof, st.config)
+        d["tables"][1]["proof"]["opening_proof"]["final_poly"]["coeffs"][0][0] ^= 1
+        assert orc.verify(st.config, vitems, wire.from_dict(d, st.config)) != 0
+        # ---- the root proof as GeneratedTxnProof { p_vals, intern }
+        ref_root, _, shrunk = orc.prove_root(st.config, rec.cfg, unit_items[0], rec)
+        root_pubs = np.concatenate([np.array([7, 6], dtype=np.uint64)] + [orc.words_digest(sp) for sp in shrunk])
+        txn = ops.AggregatableProof("Txn", root, pv)
+        j = json.loads(wire.txn_proof_to_json(txn, rec.cfg, root_pubs))
+        assert len(j["p_vals"]) == 2 and j["intern"]["public_inputs"] == [int(x) for x in root_pubs]
+        words, pis = wire.plonk_from_dict({"common": j["common"], "proof_with_pis": j["intern"]})
+        root_state = orc._plonk_state_for(rec.cfg, rec.circuit("root")[0])
+        assert (words == root).all() and orc.verify_plonk(root_state, pis, words) == 0
+        j["intern"]["proof"]["openings"]["plonk_zs"][0][0] ^= 1
+        assert orc.verify_plonk(root_state, pis, wire.plonk_from_dict({"common": j["common"], "proof_with_pis": j["intern"]})[0]) != 0
+        # ---- the block proof
+        block = leader.ProverInput(units).prove(leader.Runtime(num_workers=2))
+        ref, blk_pubs, _ = orc.prove_block(st.config, rec.cfg, unit_items, rec)
+        assert (block.intern == ref).all()
+        text = wire.block_proof_to_json(block, rec.cfg, blk_pubs)
+        h, words, pis = wire.block_proof_from_json(text)
+        blk_state = orc._plonk_state_for(rec.cfg, rec.circuit("block")[0])
+        assert h == 1 and (words == block.intern).all() and orc.verify_plonk(blk_state, pis, words) == 0
+        jb = json.loads(text)
+        jb["intern"]["public_inputs"][1] ^= 1
+        _, w2, p2 = wire.block_proof_from_json(json.dumps(jb))
+        assert orc.verify_plonk(blk_state, p2, w2) != 0
+    finally:
+        ops.P_STATE = old
+
+
 def test_failed_unit_is_requeued_once(orc, monkeypatch):
     """A unit that fails with a device error goes back on the queue once ('here' column); a second failure, or
     any other error, is fatal as in the reference (every prover error -> FatalError, /root/reference/ops/src/lib.rs:52)."""

@@ -178,3 +178,38 @@ def test_wide_routing_and_domain_separator(ctx, zk, orc):
         assert rc == 0 and (proof == ref).all() and orc.verify_plonk(ost, pub, proof) == 0
     finally:
         st.free()
+
+
+def test_gate_program_compiled_at_setup_equals_interpreter_and_oracle(ctx, zk, orc, tmp_path):
+    """A gate program that was NOT built with the library (136 wires: another operand mapping, so another kernel) is compiled by hiprtc
+    inside zk_plonk_setup, chunked (5 816 instructions), kept in the prover-state directory, and gives the oracle's proof -- as does
+    the interpreter kernel (ZK_PLONK_JIT=0, in a child process) on the same circuit."""
+    import os, subprocess, sys, hashlib
+    from eth_tx_proof_amd import plonk
+    cfg = _cfg()
+    circ, wires = plonk.recursion_circuit(degree_bits=6, seed=77, num_wires=136)
+    pub = np.array([4, 5], dtype=np.uint64)
+    wires = plonk.bind_public_inputs(circ, wires, orc.hash_no_pad(pub))
+    ost = orc.PlonkState(cfg, circ)
+    rc, ref = orc.prove_plonk(ost, wires, pub)
+    assert rc == 0
+    zk.prover_state_cache_dir(str(tmp_path))
+    try:
+        before = zk.prover_state_stats()
+        st = zk.PlonkState(ctx, cfg, circ)
+        after = zk.prover_state_stats()
+        assert after[0] == before[0] + 1                            # one kernel compiled
+        assert any(f.endswith(".co") for f in os.listdir(tmp_path))  # and persisted
+        proof = zk.prove_plonk(st, wires, pub)
+        st.free()
+        assert (proof == ref).all()
+    finally:
+        zk.prover_state_cache_dir(None)
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, hashlib, eth_tx_proof_amd as E; from eth_tx_proof_amd import lib as zl, plonk;"
+            "c = zl.Context(0); circ, w = plonk.recursion_circuit(degree_bits=6, seed=77, num_wires=136);"
+            "w = plonk.bind_public_inputs(circ, w, %r); st = zl.PlonkState(c, E.standard_recursion_config(), circ);"
+            "print(hashlib.sha256(zl.prove_plonk(st, w, np.array([4, 5], dtype=np.uint64)).tobytes()).hexdigest())"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), [int(x) for x in orc.hash_no_pad(pub)]))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_PLONK_JIT="0"), timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == hashlib.sha256(ref.tobytes()).hexdigest()

@@ -49,3 +49,36 @@ def test_wire_multi_table_and_errors(orc):
     bad = proof.copy(); bad[0] ^= np.uint64(1)
     with pytest.raises(ValueError):
         wire.to_dict(bad, cfg)
+
+
+def test_plonk_wire_round_trip(orc):
+    """ProofWithPublicInputs / GeneratedBlockProof shape for the Plonk half: exact inverse on the oracle's proof of a recursion-shaped
+    circuit, the re-read proof verifies, an edited opening or public input does not."""
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import ops, plonk, wire
+    cfg = E.standard_recursion_config()
+    circ, wires = plonk.recursion_circuit(degree_bits=6, seed=13)
+    pubs = np.array([3, 1, 4, 1, 5], dtype=np.uint64)
+    w = plonk.bind_public_inputs(circ, wires, orc.hash_no_pad(pubs))
+    st = orc.PlonkState(cfg, circ)
+    rc, proof = orc.prove_plonk(st, w, pubs)
+    assert rc == 0
+    d = wire.plonk_to_dict(proof, cfg, pubs)
+    p = d["proof_with_pis"]["proof"]
+    assert len(p["wires_cap"]) == 16 and len(p["openings"]["wires"]) == 135 and len(p["openings"]["plonk_sigmas"]) == 80
+    assert len(p["openings"]["partial_products"]) == 2 * 9 and len(p["openings"]["quotient_polys"]) == 16
+    assert len(p["opening_proof"]["query_round_proofs"]) == 28 and len(p["opening_proof"]["query_round_proofs"][0]["initial_trees_proof"]["evals_proofs"]) == 4
+    back, pis = wire.plonk_from_dict(json.loads(json.dumps(d)))
+    assert (back == proof).all() and (pis == pubs).all()
+    assert orc.verify_plonk(st, pis, back) == 0
+    blk = ops.GeneratedBlockProof(7, proof)
+    h, words, pis2 = wire.block_proof_from_json(wire.block_proof_to_json(blk, cfg, pubs))
+    assert h == 7 and (words == proof).all() and (pis2 == pubs).all()
+    d["proof_with_pis"]["proof"]["openings"]["wires"][5][1] ^= 1
+    assert orc.verify_plonk(st, pubs, wire.plonk_from_dict(d)[0]) != 0
+    d["proof_with_pis"]["proof"]["openings"]["wires"][5][1] ^= 1
+    d["proof_with_pis"]["public_inputs"][0] ^= 1
+    bw, bp = wire.plonk_from_dict(d)
+    assert orc.verify_plonk(st, bp, bw) != 0
+    with pytest.raises(ValueError):
+        wire.plonk_to_dict(proof[:-3], cfg)
