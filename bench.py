@@ -303,7 +303,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-        host_pg = sharding.host_group()       # finished proofs are host buffers: they are handed to rank 0 over gloo
+        # finished proofs are host buffers: they are handed to rank 0 over a gloo group.  gloo prints its connection report on
+        # stdout from C++: keep it away from the ONE JSON line this program owes its caller
+        sys.stdout.flush()
+        _fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            host_pg = sharding.host_group()
+        finally:
+            os.dup2(_fd1, 1)
+            os.close(_fd1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

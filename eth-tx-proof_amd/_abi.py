@@ -26,6 +26,14 @@ class HelperDesc(C.Structure):
     _fields_ = [("a0", u32), ("b0", u32), ("a1", u32), ("b1", u32)]
 
 
+CTL_MAX_EXTRA = 6
+
+
+class HelperExt(C.Structure):
+    """zk_helper_ext"""
+    _fields_ = [("filter", u32 * 2), ("n_extra", u32 * 2), ("extra", (u32 * CTL_MAX_EXTRA) * 2)]
+
+
 class LookupCol(C.Structure):
     _fields_ = [("col", u32), ("filter", u32)]
 
@@ -41,7 +49,7 @@ class Air(C.Structure):
     _fields_ = [("n_trace_cols", u32), ("n_public_inputs", u32), ("n_helpers", u32), ("n_constants", u32),
                 ("n_regs", u32), ("n_instrs", u32), ("constraint_degree", u32), ("reserved", u32),
                 ("helpers", C.POINTER(HelperDesc)), ("constants", C.POINTER(u64)), ("instrs", C.POINTER(Instr)),
-                ("lookup", C.POINTER(Lookup))]
+                ("lookup", C.POINTER(Lookup)), ("helpers_ext", C.POINTER(HelperExt))]
 
 
 class StarkConfig(C.Structure):

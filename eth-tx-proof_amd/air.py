@@ -7,7 +7,7 @@ constraint program plus logUp/CTL-shaped helper-column descriptors.
 """
 import ctypes as C
 
-from ._abi import (Air, HelperDesc, Instr, Lookup, LookupCol, NO_FILTER, OP_ADD, OP_EMIT, OP_EMIT_FIRST, OP_EMIT_LAST,
+from ._abi import (Air, CTL_MAX_EXTRA, HelperDesc, HelperExt, Instr, Lookup, LookupCol, NO_FILTER, OP_ADD, OP_EMIT, OP_EMIT_FIRST, OP_EMIT_LAST,
                    OP_EMIT_TRANSITION, OP_MUL, OP_SUB, OPND_CHALLENGE, OPND_CONST, OPND_LOCAL, OPND_NEXT, OPND_PUBLIC, OPND_REG,
                    opnd, u64)
 
@@ -15,8 +15,10 @@ from ._abi import (Air, HelperDesc, Instr, Lookup, LookupCol, NO_FILTER, OP_ADD,
 class AirProgram:
     """Owns the ctypes arrays behind a zk_air; `.air` is the struct, `.ref` a pointer to it."""
 
-    def __init__(self, n_trace_cols, n_public_inputs, helpers, constants, instrs, n_regs, num_challenges=2, lookup=None):
-        """lookup: None or (looked [(col, filter_col or None)], table_col, freq_col) -- a logUp argument inside the table"""
+    def __init__(self, n_trace_cols, n_public_inputs, helpers, constants, instrs, n_regs, num_challenges=2, lookup=None, helpers_ext=None):
+        """lookup: None or (looked [(col, filter_col or None)], table_col, freq_col) -- a logUp argument inside the table.
+        helpers_ext: None or one (filter0, filter1, extra0, extra1) per helper: filter columns (None: constant 1) and the further columns
+        of each pair's column set (zk_helper_ext: CTL helpers with filters and column sets of more than two columns)"""
         self.n_trace_cols = n_trace_cols
         self.n_helpers = len(helpers)
         self.n_aux_cols = num_challenges * (len(helpers) + 1) if helpers else 0
@@ -31,10 +33,25 @@ class AirProgram:
         self._helpers = (HelperDesc * max(1, len(helpers)))(*[HelperDesc(*h) for h in helpers])
         self._constants = (u64 * max(1, len(constants)))(*constants)
         self._instrs = (Instr * max(1, len(instrs)))(*[Instr(*i) for i in instrs])
+        self.helpers_ext = helpers_ext
+        self._helpers_ext = None
+        if helpers_ext is not None:
+            assert len(helpers_ext) == len(helpers)
+            self._helpers_ext = (HelperExt * max(1, len(helpers_ext)))()
+            for m, (f0, f1, e0, e1) in enumerate(helpers_ext):
+                x = self._helpers_ext[m]
+                x.filter[0], x.filter[1] = (NO_FILTER if f0 is None else f0), (NO_FILTER if f1 is None else f1)
+                x.n_extra[0], x.n_extra[1] = len(e0), len(e1)
+                assert len(e0) <= CTL_MAX_EXTRA and len(e1) <= CTL_MAX_EXTRA
+                for i, c in enumerate(e0):
+                    x.extra[0][i] = c
+                for i, c in enumerate(e1):
+                    x.extra[1][i] = c
         self.air = Air(n_trace_cols, n_public_inputs, len(helpers), len(constants), n_regs, len(instrs), 3, 0,
                        C.cast(self._helpers, C.POINTER(HelperDesc)), C.cast(self._constants, C.POINTER(u64)),
                        C.cast(self._instrs, C.POINTER(Instr)),
-                       C.pointer(self._lookup) if self._lookup is not None else C.POINTER(Lookup)())
+                       C.pointer(self._lookup) if self._lookup is not None else C.POINTER(Lookup)(),
+                       C.cast(self._helpers_ext, C.POINTER(HelperExt)) if self._helpers_ext is not None else C.POINTER(HelperExt)())
         self.ref = C.pointer(self.air)
         self.n_instrs = len(instrs)
 
@@ -177,4 +194,61 @@ def lookup_air(n_looked=5, filtered=(1, 3), log_n=8, seed=1, num_challenges=2):
         ins += [(OP_SUB, 0, L(z), h), (OP_EMIT_LAST, 0, R(0), 0),
                 (OP_SUB, 0, L(z), N(z)), (OP_SUB, 0, R(0), h), (OP_EMIT_TRANSITION, 0, R(0), 0)]
     prog = AirProgram(n_cols, 0, helpers, [1, 0], ins, 6, num_challenges, lookup=(looked, 0, 1))
+    return prog, np.ascontiguousarray(trace % np.uint64(P)), np.zeros(0, dtype=np.uint64)
+
+
+def ctl_air(n_sets=6, log_n=7, seed=1, num_challenges=2):
+    """A table whose auxiliary columns are cross-table-lookup helpers in upstream's full form (starky::cross_table_lookup::partial_sums,
+    SURVEY.md A9): every helper sums  filter / combine(column set)  over two (column set, filter) pairs -- column sets of 2 to 5 columns,
+    some pairs filtered by a 0/1 column, some not -- and Z is the suffix sum of all helpers.  Constraints (emission order = spec), per
+    challenge j and helper m with x_k = combine_j(set k):   h x_0 x_1 - f_0 x_1 - f_1 x_0,   then  Z = sum_m h  on the last row and
+    Z - Z' - sum_m h  on every transition.  Returns (AirProgram, trace uint64 (cols, n), public inputs (none))."""
+    import numpy as np
+    P = 0xFFFFFFFF00000001
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    n_val, n_flt = 10, 3                    # value columns 0..9, then three 0/1 filter columns
+    n_cols = n_val + n_flt
+    trace = rng.integers(0, 1 << 62, size=(n_cols, n), dtype=np.uint64)
+    trace[n_val:] = rng.integers(0, 2, size=(n_flt, n), dtype=np.uint64)
+    sets = []                               # (columns, filter or None)
+    for k in range(n_sets):
+        ln = 2 + k % 4
+        cols = [int(c) for c in rng.choice(n_val, size=ln, replace=False)]
+        sets.append((cols, (n_val + k % n_flt) if k % 3 != 2 else None))
+    assert n_sets % 2 == 0
+    helpers, ext = [], []
+    for m in range(n_sets // 2):
+        (c0, f0), (c1, f1) = sets[2 * m], sets[2 * m + 1]
+        helpers.append((c0[0], c0[1], c1[0], c1[1]))
+        ext.append((f0, f1, c0[2:], c1[2:]))
+    H = len(helpers)
+    R = lambda i: opnd(OPND_REG, i)
+    L = lambda i: opnd(OPND_LOCAL, i)
+    N = lambda i: opnd(OPND_NEXT, i)
+    K = lambda i: opnd(OPND_CONST, i)
+    CH = lambda i: opnd(OPND_CHALLENGE, i)
+    ins = []
+    for j in range(num_challenges):
+        beta, gamma = CH(2 * j), CH(2 * j + 1)
+
+        def combine(dst, cols):             # Horner from the last column: ((c_last beta + ..) beta + c_0) + gamma
+            ins.append((OP_ADD, dst, L(cols[-1]), K(1)))
+            for c in reversed(cols[:-1]):
+                ins.extend([(OP_MUL, dst, R(dst), beta), (OP_ADD, dst, R(dst), L(c))])
+            ins.append((OP_ADD, dst, R(dst), gamma))
+        for m in range(H):
+            (c0, f0), (c1, f1) = sets[2 * m], sets[2 * m + 1]
+            h = L(n_cols + j * H + m)
+            combine(0, c0)
+            combine(1, c1)
+            ins += [(OP_MUL, 2, R(0), R(1)), (OP_MUL, 2, R(2), h)]
+            ins += [(OP_MUL, 3, L(f0), R(1))] if f0 is not None else [(OP_ADD, 3, R(1), K(1))]
+            ins += [(OP_MUL, 4, L(f1), R(0))] if f1 is not None else [(OP_ADD, 4, R(0), K(1))]
+            ins += [(OP_SUB, 2, R(2), R(3)), (OP_SUB, 2, R(2), R(4)), (OP_EMIT, 0, R(2), 0)]
+            ins += [(OP_ADD, 5, R(5), h)] if m else [(OP_ADD, 5, h, K(1))]
+        z = n_cols + num_challenges * H + j
+        ins += [(OP_SUB, 0, L(z), R(5)), (OP_EMIT_LAST, 0, R(0), 0),
+                (OP_SUB, 0, L(z), N(z)), (OP_SUB, 0, R(0), R(5)), (OP_EMIT_TRANSITION, 0, R(0), 0)]
+    prog = AirProgram(n_cols, 0, helpers, [1, 0], ins, 6, num_challenges, helpers_ext=ext)
     return prog, np.ascontiguousarray(trace % np.uint64(P)), np.zeros(0, dtype=np.uint64)

@@ -10,11 +10,12 @@ struct DevAir {
     zk_instr *d_instrs;
     u64 *d_constants;
     zk_helper_desc *d_helpers;
+    zk_helper_ext *d_helpers_ext;      // nullptr: plain pairs
     u32 n_aux(u32 nch) const { return zk_air_n_aux(host, nch); }
 };
 
 // prover_aux.hip
-int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc *d_helpers, u32 nch, const u64 *d_chal,
+int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc *d_helpers, const zk_helper_ext *d_helpers_ext, u32 nch, const u64 *d_chal,
                            const u64 *d_trace, u32 log_n, u64 *d_aux);
 
 // prover_quotient.hip: compute_quotient_polys -> d_qcoeffs: (nch << rate_bits) columns of n coefficients, natural order

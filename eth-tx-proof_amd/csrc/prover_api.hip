@@ -31,6 +31,13 @@ int32_t zk_air_validate(const zk_air *air, uint32_t nch) {
     for (u32 m = 0; m < air->n_helpers; m++) {
         const zk_helper_desc &h = air->helpers[m];
         if (h.a0 >= C || h.b0 >= C || h.a1 >= C || h.b1 >= C) return ZK_ERR_INVALID_ARG;
+        if (air->helpers_ext) {
+            const zk_helper_ext &x = air->helpers_ext[m];
+            for (int k = 0; k < 2; k++) {
+                if (x.n_extra[k] > ZK_CTL_MAX_EXTRA || (x.filter[k] != ZK_NO_FILTER && x.filter[k] >= C)) return ZK_ERR_INVALID_ARG;
+                for (u32 i = 0; i < x.n_extra[k]; i++) if (x.extra[k][i] >= C) return ZK_ERR_INVALID_ARG;
+            }
+        }
     }
     auto src_ok = [&](u32 o) {
         const u32 kind = o >> 24, idx = o & 0xFFFFFFu;
@@ -66,19 +73,21 @@ int32_t zk_aux_columns(zk_ctx *ctx, const zk_air *air, uint32_t num_challenges, 
     u64 *d_tr = (u64 *)ctx->alloc(n * air->n_trace_cols * sizeof(u64)), *d_aux = (u64 *)ctx->alloc(n * A * sizeof(u64));
     u64 *d_ch = (u64 *)ctx->alloc(2 * num_challenges * sizeof(u64));
     zk_helper_desc *d_h = (zk_helper_desc *)ctx->alloc(air->n_helpers * sizeof(zk_helper_desc));
-    int32_t rc = (d_tr && d_aux && d_ch && d_h) ? ZK_OK : ZK_ERR_OOM;
+    zk_helper_ext *d_x = (air->helpers_ext && air->n_helpers) ? (zk_helper_ext *)ctx->alloc(air->n_helpers * sizeof(zk_helper_ext)) : nullptr;
+    int32_t rc = (d_tr && d_aux && d_ch && d_h && (d_x || !(air->helpers_ext && air->n_helpers))) ? ZK_OK : ZK_ERR_OOM;
     std::vector<u64> ch(challenges, challenges + 2 * num_challenges);
     for (auto &v : ch) v = gl_canon(v);
     if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_tr, trace, n * air->n_trace_cols * sizeof(u64));
     if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_ch, ch.data(), ch.size() * sizeof(u64));
     if (rc == ZK_OK) rc = zk_dev_upload(ctx, d_h, air->helpers, air->n_helpers * sizeof(zk_helper_desc));
+    if (rc == ZK_OK && d_x) rc = zk_dev_upload(ctx, d_x, air->helpers_ext, air->n_helpers * sizeof(zk_helper_ext));
     // the trace is used as given by the helper kernel: canonicalise it through a commit-free pass
-    if (rc == ZK_OK) rc = zk_aux_columns_dev(ctx, air, d_h, num_challenges, d_ch, d_tr, log_n, d_aux);
+    if (rc == ZK_OK) rc = zk_aux_columns_dev(ctx, air, d_h, d_x, num_challenges, d_ch, d_tr, log_n, d_aux);
     if (rc == ZK_OK) rc = zk_dev_download(ctx, aux_out, d_aux, n * A * sizeof(u64));
     u64 err = 0;
     if (rc == ZK_OK) rc = zk_dev_download(ctx, &err, ctx->d_err, sizeof(u64));
     if (rc == ZK_OK && err) { rc = (int32_t)(uint32_t)err; hipMemsetAsync(ctx->d_err, 0, sizeof(u64), ctx->stream); }
-    ctx->release(d_tr); ctx->release(d_aux); ctx->release(d_ch); ctx->release(d_h);
+    ctx->release(d_tr); ctx->release(d_aux); ctx->release(d_ch); ctx->release(d_h); ctx->release(d_x);
     return rc;
 }
 
@@ -99,7 +108,7 @@ int32_t zk_quotient(zk_ctx *ctx, const zk_stark_config *cfg, const zk_air *air, 
     DevAir da; da.host = air;
     da.d_instrs = (zk_instr *)ctx->alloc((size_t)(air->n_instrs ? air->n_instrs : 1) * sizeof(zk_instr));
     da.d_constants = (u64 *)ctx->alloc((size_t)(air->n_constants ? air->n_constants : 1) * sizeof(u64));
-    da.d_helpers = nullptr;
+    da.d_helpers = nullptr; da.d_helpers_ext = nullptr;
     u64 *d_pub = (u64 *)ctx->alloc((size_t)(air->n_public_inputs ? air->n_public_inputs : 1) * sizeof(u64));
     u64 *d_ch = (u64 *)ctx->alloc(16 * sizeof(u64)), *d_al = (u64 *)ctx->alloc(8 * sizeof(u64));
     u64 *d_q = (u64 *)ctx->alloc((size_t)nch * L * sizeof(u64));

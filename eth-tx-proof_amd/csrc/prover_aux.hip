@@ -26,9 +26,18 @@ __device__ __forceinline__ u64 gl_inv_dev(u64 a) {
 }
 
 #define AUX_CHUNK 8
+// combine(cols) + gamma of one pair: t[a] + beta t[b] (+ beta^2 t[e0] + ..) + gamma, Horner from the last column
+__device__ __forceinline__ u64 ctl_combine(const u64 *__restrict__ trace, size_t n, size_t r, u32 a, u32 b, const zk_helper_ext *x, int k, u64 beta, u64 gamma) {
+    if (!x || x->n_extra[k] == 0) return gl_add(gl_mul_add(beta, trace[(size_t)b * n + r], trace[(size_t)a * n + r]), gamma);
+    u64 acc = trace[(size_t)x->extra[k][x->n_extra[k] - 1] * n + r];
+    for (u32 i = x->n_extra[k] - 1; i-- > 0;) acc = gl_mul_add(acc, beta, trace[(size_t)x->extra[k][i] * n + r]);
+    acc = gl_mul_add(acc, beta, trace[(size_t)b * n + r]);
+    acc = gl_mul_add(acc, beta, trace[(size_t)a * n + r]);
+    return gl_add(acc, gamma);
+}
 __global__ __launch_bounds__(256) void aux_helpers_kernel(const u64 *__restrict__ trace, size_t n, const zk_helper_desc *__restrict__ helpers,
-                                                          u32 H, u32 nch, const u64 *__restrict__ chal, u64 *__restrict__ aux,
-                                                          u64 *__restrict__ rowsum, u64 *err) {
+                                                          const zk_helper_ext *__restrict__ ext, u32 H, u32 nch, const u64 *__restrict__ chal,
+                                                          u64 *__restrict__ aux, u64 *__restrict__ rowsum, u64 *err) {
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     u32 j = blockIdx.y;
     if (r >= n) return;
@@ -41,9 +50,13 @@ __global__ __launch_bounds__(256) void aux_helpers_kernel(const u64 *__restrict_
         for (int k = 0; k < AUX_CHUNK; k++) {
             if (m0 + k < H) {
                 zk_helper_desc d = helpers[m0 + k];
-                u64 x1 = gl_add(gl_mul_add(beta, trace[(size_t)d.b0 * n + r], trace[(size_t)d.a0 * n + r]), gamma);
-                u64 x2 = gl_add(gl_mul_add(beta, trace[(size_t)d.b1 * n + r], trace[(size_t)d.a1 * n + r]), gamma);
-                num[k] = gl_add(x1, x2); den[k] = gl_mul(x1, x2);
+                const zk_helper_ext *x = ext ? ext + (m0 + k) : nullptr;
+                u64 x1 = ctl_combine(trace, n, r, d.a0, d.b0, x, 0, beta, gamma);
+                u64 x2 = ctl_combine(trace, n, r, d.a1, d.b1, x, 1, beta, gamma);
+                // f_0 / x1 + f_1 / x2 = (f_0 x2 + f_1 x1) / (x1 x2); a filter is a 0/1 trace column, or absent (constant 1)
+                const u64 f0 = (x && x->filter[0] != ZK_NO_FILTER) ? trace[(size_t)x->filter[0] * n + r] : 1;
+                const u64 f1 = (x && x->filter[1] != ZK_NO_FILTER) ? trace[(size_t)x->filter[1] * n + r] : 1;
+                num[k] = x ? gl_add(gl_mul(f0, x2), gl_mul(f1, x1)) : gl_add(x1, x2); den[k] = gl_mul(x1, x2);
             } else { num[k] = 0; den[k] = 1; }
             pre[k] = acc;
             acc = gl_mul(acc, den[k]);
@@ -173,7 +186,7 @@ static int32_t lookup_columns_dev(zk_ctx *ctx, const zk_lookup *lk, u32 nch, con
     return ZK_OK;
 }
 
-int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc *d_helpers, u32 nch, const u64 *d_chal,
+int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc *d_helpers, const zk_helper_ext *d_helpers_ext, u32 nch, const u64 *d_chal,
                            const u64 *d_trace, u32 log_n, u64 *d_aux) {
     u32 H = air->n_helpers;
     size_t n = (size_t)1 << log_n;
@@ -187,7 +200,7 @@ int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc 
     u32 nb = (u32)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     u64 *blocksum = (u64 *)ctx->alloc((size_t)nb * nch * sizeof(u64));
     if (!rowsum || !blocksum) return ZK_ERR_OOM;
-    ZK_LAUNCH(ctx, "aux_helpers", aux_helpers_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, d_trace, n, d_helpers, H, nch, d_chal,
+    ZK_LAUNCH(ctx, "aux_helpers", aux_helpers_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, d_trace, n, d_helpers, d_helpers_ext, H, nch, d_chal,
               d_aux, rowsum, ctx->d_err);
     ZK_LAUNCH(ctx, "aux_scan_sums", scan_block_sums_kernel, dim3(nb, nch), dim3(256), 0, (const u64 *)rowsum, n, blocksum);
     ZK_LAUNCH(ctx, "aux_scan_suffix", scan_block_suffix_kernel, dim3(nch), dim3(64), 0, blocksum, nb);

@@ -186,6 +186,12 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
             if ((rc = ctx->upload_small(dair[t].d_constants, c.data(), c.size() * sizeof(u64))) != ZK_OK) return rc;
         }
         if (a->n_helpers && (rc = ctx->upload_small(dair[t].d_helpers, a->helpers, a->n_helpers * sizeof(zk_helper_desc))) != ZK_OK) return rc;
+        dair[t].d_helpers_ext = nullptr;
+        if (a->n_helpers && a->helpers_ext) {
+            dair[t].d_helpers_ext = (zk_helper_ext *)A_((size_t)a->n_helpers * sizeof(zk_helper_ext));
+            if (!dair[t].d_helpers_ext) return ZK_ERR_OOM;
+            if ((rc = ctx->upload_small(dair[t].d_helpers_ext, a->helpers_ext, a->n_helpers * sizeof(zk_helper_ext))) != ZK_OK) return rc;
+        }
         if (a->n_public_inputs) {
             std::vector<u64> c(tables[t].public_inputs, tables[t].public_inputs + a->n_public_inputs);
             for (auto &v : c) v = gl_canon(v);
@@ -239,7 +245,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
             ProfScope ph(ctx, "phase: compute auxiliary polynomials commitment");
             u64 *d_aux = (u64 *)ctx->alloc((size_t)A * n * sizeof(u64));
             if (!d_aux) { rc = ZK_ERR_OOM; break; }
-            rc = zk_aux_columns_dev(ctx, air, dair[t].d_helpers, nch, d_chal, d_trace[t], log_n, d_aux);
+            rc = zk_aux_columns_dev(ctx, air, dair[t].d_helpers, dair[t].d_helpers_ext, nch, d_chal, d_trace[t], log_n, d_aux);
             if (rc == ZK_OK) rc = zk_batch_commit_dev(ctx, d_aux, log_n, A, cfg.rate_bits, cfg.cap_height, 1, &aux_b[t]);
             ctx->release(d_aux);
             if (rc) break;

@@ -176,11 +176,19 @@ enum {
 #define ZK_OPND(kind, idx) (((uint32_t)(kind) << 24) | (uint32_t)(idx))
 typedef struct { uint32_t op, dst, a, b; } zk_instr;
 
-/* One logUp/CTL-shaped helper column (starky::lookup / cross_table_lookup::partial_sums):
+/* One CTL-shaped helper column (starky::cross_table_lookup::partial_sums), plain form (see zk_helper_ext for filters and longer column sets):
  *   h[row] = 1/(t[a0] + beta*t[b0] + gamma) + 1/(t[a1] + beta*t[b1] + gamma)        (t = trace columns)
  * For every challenge set j the auxiliary columns are  [h_0 .. h_{H-1}, Z]  with the suffix sum
  *   Z[row] = sum_{s >= row} sum_m h_m[s].                                                            */
 typedef struct { uint32_t a0, b0, a1, b1; } zk_helper_desc;
+/* Optional refinement of helper m (zk_air.helpers_ext, n_helpers entries, or NULL for plain pairs) -- starky's CTL helper column in full
+ * (cross_table_lookup::partial_sums): a sum over at most two (column set, filter) pairs of
+ *     filter[row] / combine(cols)[row],   combine(cols) = cols[0] + beta cols[1] + beta^2 cols[2] + .. + gamma.
+ * Pair k of helper m has the columns (a_k, b_k) of zk_helper_desc followed by n_extra[k] more (extra[k][..]: at most ZK_CTL_MAX_EXTRA, so
+ * column sets of 2 .. 8 columns) and the 0/1 filter column filter[k] (ZK_NO_FILTER: constant 1):
+ *     h_m[row] = f_0 / (t[a0] + beta t[b0] + beta^2 t[e0_0] + .. + gamma) + f_1 / (t[a1] + beta t[b1] + beta^2 t[e1_0] + .. + gamma). */
+#define ZK_CTL_MAX_EXTRA 6
+typedef struct { uint32_t filter[2]; uint32_t n_extra[2]; uint32_t extra[2][ZK_CTL_MAX_EXTRA]; } zk_helper_ext;
 
 /* A logUp lookup argument inside one table (starky::lookup::{Lookup, lookup_helper_columns}): looked columns f_i, each
  * with an optional 0/1 filter column, are checked against a table column t with a multiplicity column m.  For every challenge set j
@@ -211,6 +219,7 @@ typedef struct {
     const uint64_t *constants;
     const zk_instr *instrs;
     const zk_lookup *lookup;   /* optional (NULL: none): adds num_challenges * (ceil(lookup->n_cols / 2) + 1) auxiliary columns in front */
+    const zk_helper_ext *helpers_ext;   /* optional (NULL: every helper is two plain, unfiltered pairs) */
 } zk_air;
 /* number of auxiliary columns of an AIR: lookup columns first, CTL-shaped columns last */
 static inline uint32_t zk_air_n_aux(const zk_air *air, uint32_t num_challenges) {

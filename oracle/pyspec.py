@@ -414,16 +414,21 @@ def _path(levels, idx):
     return out
 
 
-def _aux_columns(helpers, nch, chal, trace, n):
+def _aux_columns(helpers, nch, chal, trace, n, helpers_ext=None):
+    """CTL helper columns and Z; helpers_ext[m] = (filter0, filter1, extra0, extra1) refines helper m: filter / combine(column set)"""
     H = len(helpers)
     cols = [[0] * n for _ in range(nch * (H + 1))]
     for j in range(nch):
         beta, gamma = chal[2 * j], chal[2 * j + 1]
         for m, (a0, b0, a1, b1) in enumerate(helpers):
+            f0, f1, e0, e1 = helpers_ext[m] if helpers_ext else (None, None, [], [])
+            s0, s1 = [a0, b0] + list(e0), [a1, b1] + list(e1)
             for r in range(n):
-                d0 = (trace[a0][r] + beta * trace[b0][r] + gamma) % P
-                d1 = (trace[a1][r] + beta * trace[b1][r] + gamma) % P
-                cols[j * H + m][r] = (inv(d0) + inv(d1)) % P
+                d0 = (sum(trace[c][r] * pow(beta, i, P) for i, c in enumerate(s0)) + gamma) % P
+                d1 = (sum(trace[c][r] * pow(beta, i, P) for i, c in enumerate(s1)) + gamma) % P
+                v0 = trace[f0][r] if f0 is not None else 1
+                v1 = trace[f1][r] if f1 is not None else 1
+                cols[j * H + m][r] = (v0 * inv(d0) + v1 * inv(d1)) % P
         run = 0
         for r in range(n - 1, -1, -1):
             run = (run + sum(cols[j * H + m][r] for m in range(H))) % P
@@ -482,7 +487,7 @@ def prove_tables(cfg, tables):
         out += [k, C, A] + [w for h in b["cap"] for w in h]
         ab = None
         if A:
-            ab = commit_values(_aux_columns(t["helpers"], nch, chal, t["trace"], n), rb, ch_h)
+            ab = commit_values(_aux_columns(t["helpers"], nch, chal, t["trace"], n, t.get("helpers_ext")), rb, ch_h)
             for h in ab["cap"]:
                 ch.observe_many(h)
             out += [w for h in ab["cap"] for w in h]

@@ -101,15 +101,26 @@ int32_t orc_aux_columns(const zk_air *air, uint32_t nch, const uint64_t *ch, con
             uint64_t *h = aux + (size_t)(j * H + m) * n;
             /* batch_multiplicative_inverse (Montgomery trick) over the 2n denominators of this column */
             uint64_t *den = (uint64_t *)malloc(2 * n * sizeof(uint64_t)), *pre = (uint64_t *)malloc(2 * n * sizeof(uint64_t));
-            for (size_t r = 0; r < n; r++) {
-                den[2 * r] = gl_add(gl_add(trace[(size_t)d->a0 * n + r], gl_mul(beta, trace[(size_t)d->b0 * n + r])), gamma);
-                den[2 * r + 1] = gl_add(gl_add(trace[(size_t)d->a1 * n + r], gl_mul(beta, trace[(size_t)d->b1 * n + r])), gamma);
-            }
+            /* partial_sums: combine(cols) = cols[0] + beta cols[1] + beta^2 cols[2] + .. + gamma for each of the two column sets */
+            const zk_helper_ext *x = air->helpers_ext ? &air->helpers_ext[m] : NULL;
+            for (size_t r = 0; r < n; r++)
+                for (int k = 0; k < 2; k++) {
+                    uint32_t cols[2 + ZK_CTL_MAX_EXTRA], nc = 0;
+                    cols[nc++] = k ? d->a1 : d->a0; cols[nc++] = k ? d->b1 : d->b0;
+                    if (x) for (uint32_t i = 0; i < x->n_extra[k]; i++) cols[nc++] = x->extra[k][i];
+                    uint64_t acc = 0, bp = 1;
+                    for (uint32_t i = 0; i < nc; i++) { acc = gl_add(acc, gl_mul(bp, trace[(size_t)cols[i] * n + r])); bp = gl_mul(bp, beta); }
+                    den[2 * r + k] = gl_add(acc, gamma);
+                }
             uint64_t acc = 1;
             for (size_t i = 0; i < 2 * n; i++) { pre[i] = acc; if (den[i] == 0) bad = 1; acc = gl_mul(acc, den[i]); }
             uint64_t inv = gl_inv(acc);
             for (size_t i = 2 * n; i-- > 0;) { uint64_t t = gl_mul(inv, pre[i]); inv = gl_mul(inv, den[i]); den[i] = t; }
-            for (size_t r = 0; r < n; r++) h[r] = gl_add(den[2 * r], den[2 * r + 1]);
+            for (size_t r = 0; r < n; r++) {        /* sum of filter / combine over the two pairs (filter absent: 1) */
+                uint64_t f0 = (x && x->filter[0] != ZK_NO_FILTER) ? trace[(size_t)x->filter[0] * n + r] : 1;
+                uint64_t f1 = (x && x->filter[1] != ZK_NO_FILTER) ? trace[(size_t)x->filter[1] * n + r] : 1;
+                h[r] = gl_add(gl_mul(f0, den[2 * r]), gl_mul(f1, den[2 * r + 1]));
+            }
             free(den); free(pre);
         }
         /* Z[r] = sum_{s>=r} sum_m h_m[s]  (suffix sum, computed from the last row backwards) */

@@ -28,6 +28,24 @@ def test_aux_columns(ctx, zk, orc, n_cols, n_helpers, log_n):
         assert int(got[2 * H + j, -1]) == sum(int(got[j * H + m, -1]) for m in range(H)) % P
 
 
+@pytest.mark.parametrize("n_sets,log_n", [(2, 4), (6, 7), (10, 11), (16, 13)])
+def test_ctl_helpers_with_filters_and_column_sets(ctx, zk, orc, n_sets, log_n):
+    """CTL helper columns in upstream's full form -- sum over two (column set, filter) pairs of filter / combine(cols), column sets of
+    2..5 columns (zk_helper_ext) -- on the GPU: the columns equal the oracle's, and the whole proof of the table (constraints over those
+    columns, the interpreter and -- at 2^13 rows -- nothing else changes) equals the oracle's word for word and verifies."""
+    from eth_tx_proof_amd import air
+    prog, tr, pub = air.ctl_air(n_sets=n_sets, log_n=log_n, seed=n_sets)
+    ch = field_rand(np.random.default_rng(2), 4)
+    got = zk.aux_columns(ctx, prog, ch, tr)
+    rc, ref = orc.aux_columns(prog, ch, tr)
+    assert rc == 0 and (got == ref).all()
+    cfg = _cfg()
+    proof = zk.prove_tables(ctx, cfg, [(prog, log_n, tr, pub)])
+    rc, want = orc.prove(cfg, [(prog, log_n, tr, pub)])
+    assert rc == 0 and proof.size == want.size and (proof == want).all()
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0
+
+
 @pytest.mark.parametrize("n_cols,n_helpers,log_n", [(6, 2, 7), (93, 19, 9), (7, 0, 8)])
 def test_quotient_polys(ctx, zk, orc, n_cols, n_helpers, log_n):
     from eth_tx_proof_amd import air
