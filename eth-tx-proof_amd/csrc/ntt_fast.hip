@@ -49,7 +49,17 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
     } else {
         size_t tiles_per_block = ((size_t)1 << S) >> TL, tiles_per_col = (n >> (W + S)) * tiles_per_block;
         size_t rem;
-        if (p.col_fast) { col = blockIdx.x % p.n_cols; rem = blockIdx.x / p.n_cols; }
+        if (p.col_fast == 2) {
+            // XCD-paired order.  A TILE run is T = 2^TL adjacent elements; at W = 10 that is 8 elements = 64 bytes, HALF a 128-byte
+            // line, and the workgroup holding the other half used to come n_cols workgroups later on another XCD (another L2): the
+            // TILE passes fetched every line twice (FETCH_SIZE 2.14x the data against 1.09x for ROW passes and for TILE passes at
+            // W = 9, profiles/r03e_pmc_tile_fetch_ab_and_whole_proof.json).  Workgroups go to the XCDs round robin (blockIdx % 8), so
+            // blockIdx b and b + 8 are consecutive on one XCD: give those two the two halves of the same lines.
+            const u32 b = blockIdx.x, xcd = b & 7u, m = b >> 3;
+            const u32 l = (m & 1u) + 2u * (xcd + 8u * (m >> 1));
+            const u32 pair = l >> 1;
+            col = pair % p.n_cols; rem = 2 * (size_t)(pair / p.n_cols) + (l & 1u);
+        } else if (p.col_fast) { col = blockIdx.x % p.n_cols; rem = blockIdx.x / p.n_cols; }
         else { col = blockIdx.x / tiles_per_col; rem = blockIdx.x % tiles_per_col; }
         base = ((rem / tiles_per_block) << (W + S)) + ((rem % tiles_per_block) << TL);
     }
@@ -436,6 +446,12 @@ bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, con
     size_t rows_per_col = ((size_t)1 << p.k) >> p.W;
     bool cf_on = row ? (use_colfast & 1) : (use_colfast & 2);
     p.col_fast = cf_on ? (row ? (rows_per_col >= ((size_t)1 << p.TL) ? 1 : 0) : 1) : 0;
+    if (!row && p.col_fast) {
+        // runs shorter than a 128-byte line: pair the two workgroups that share lines on one XCD (kernel comment); needs whole groups of 16
+        static const int xcd_pair = getenv("ZK_NTT_XCD_PAIR") ? atoi(getenv("ZK_NTT_XCD_PAIR")) : 1;
+        const size_t tiles_per_col = (((size_t)1 << p.k) >> p.W) >> p.TL, blocks = tiles_per_col * (size_t)p.n_cols;
+        if (xcd_pair && p.TL < 4 && p.S > p.TL && (tiles_per_col % 2) == 0 && (blocks % 16) == 0) p.col_fast = 2;
+    }
     if (dit) return row ? launch_dr<true, true>(ctx, p, name) : launch_dr<true, false>(ctx, p, name);
     return row ? launch_dr<false, true>(ctx, p, name) : launch_dr<false, false>(ctx, p, name);
 }

@@ -75,8 +75,9 @@ int32_t zk_dev_download(zk_ctx *ctx, void *dst, const void *d_src, size_t bytes)
  * two pinned chunks of the context (the CPU fills one while the DMA engine drains the other). */
 int32_t zk_host_alloc(zk_ctx *ctx, size_t bytes, void **h_ptr);
 int32_t zk_host_free(zk_ctx *ctx, void *h_ptr);
-/* Prefetch for a single worker: start uploading the NEXT unit's trace (n_words u64, pinned or pageable) on the context's copy
- * stream and return at once; *d_ptr is device memory owned by the context (zk_dev_free it after the proof).  zk_prove_tables /
+/* Prefetch for a single worker: start uploading the NEXT unit's trace (n_words u64) on the context's copy stream; *d_ptr is device
+ * memory owned by the context (zk_dev_free it after the proof).  Returns at once for a PINNED source (zk_host_alloc); a pageable source
+ * is staged through the context's pinned chunks by the calling thread, so the call returns when the CPU has copied the last chunk.  zk_prove_tables /
  * zk_prove_plonk given this pointer (trace_on_device = 1) first wait, on the device, for the upload that fills it -- and only for
  * that one, so a prefetch of the unit after next never holds a proof back.  Call it BEFORE the zk_prove_tables of the current
  * unit so that the copy overlaps that proof. */
@@ -296,7 +297,10 @@ int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *cfg, uint32_
  * ZK_PROVER_STATE_DIR read at first use; NULL or "" switches persistence off), every constraint kernel that hiprtc compiles is
  * written to  <dir>/prover_state_<digest>.gfx950.co  where <digest> names the AIR (program, column counts, challenges,
  * rate_bits), and a later process start loads the code object from there instead of compiling.  A file that is missing, truncated,
- * for another program or fails its checksum is ignored and rebuilt (the reference warns and regenerates likewise).  Process-wide.
+ * for another program or fails its checksum is ignored and rebuilt (the reference warns and regenerates likewise); the file's key holds
+ * the GPU architecture and the hiprtc version, and an image that does not load on this device is deleted and rebuilt.  The directory is
+ * TRUSTED: its files are GPU code that this process will run (the checksum guards against damage, not against an attacker who can write
+ * there) -- give it the permissions of the binary itself.  Process-wide.
  * zk_prover_state_stats: kernels compiled by hiprtc / loaded from disk so far in this process. */
 int32_t zk_prover_state_cache_dir(const char *dir);
 int32_t zk_prover_state_stats(uint64_t *compiled, uint64_t *loaded_from_disk);
