@@ -98,12 +98,15 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
 // fault hunt of round 2 (tools/stress_faults.py: 8 streams x 100 full-size proofs x {build-time, hiprtc, interpreter} kernels x
 // {plain, fence allocator, a scratch-resident kernel between the real ones, mutex off}, each in a fresh process:
 // profiles/r02g_stress_faults.jsonl) ran 9600 proofs without a fault or a differing proof word, with the mutex off as well, so
-// the serialisation is off by default; ZK_COLD_MUTEX=1 brings it back.
+// the serialisation is off by default; ZK_COLD_MUTEX=1 brings it back.  That hunt prepared the kernels on one thread first: the one
+// scenario it did not cover -- several threads compiling and loading code objects at their FIRST proofs (ZK_QUOTIENT_JIT=1 / 2: hiprtc at
+// first use) -- keeps the mutex unless ZK_COLD_MUTEX=0 says otherwise.
 extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
                                    uint64_t *proof_out, size_t cap_words, size_t *len_words) {
     static std::atomic<bool> warm{false};
     static std::mutex cold_mu;
-    static const bool cold = getenv("ZK_COLD_MUTEX") && atoi(getenv("ZK_COLD_MUTEX"));
+    static const bool cold_env = getenv("ZK_COLD_MUTEX") != nullptr, cold_on = cold_env && atoi(getenv("ZK_COLD_MUTEX"));
+    const bool cold = cold_env ? cold_on : (ctx && ctx->quotient_jit_mode >= 1);
     if (!cold || warm.load(std::memory_order_acquire)) return prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
     std::lock_guard<std::mutex> lk(cold_mu);
     int32_t rc = prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);

@@ -51,7 +51,10 @@ class Runtime:
                         on_result(i, res[k])
                 except ops.FatalError as e:
                     code = getattr(e.__cause__, "code", None)
-                    if code in DEVICE_ERRORS and tries < self.max_requeue:
+                    # a unit whose traces live in the failed context's device memory cannot go to another context: only units with
+                    # host-resident inputs are re-queued
+                    movable = all(not isinstance(t.trace, (int, np.integer)) for t in getattr(inputs[k], "tables", []))
+                    if code in DEVICE_ERRORS and tries < self.max_requeue and movable:
                         with lock:
                             self.requeued.append((i, str(e)))
                         ops.p_state().drop_ctx()        # this worker starts over on a fresh context / stream / allocator
