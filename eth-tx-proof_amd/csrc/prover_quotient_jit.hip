@@ -45,6 +45,7 @@ void appendf(std::string &s, const char *fmt, ...) {
 // C++ expression for an operand; emits the (single) load of a column / public input / challenge at its first use
 struct Gen {
     const zk_air *air; u32 C, A;
+    bool fenced = false;       // loads through the eval lambda's local base pointers tp / tn / ap_ / an (generate(): fences every QJIT_FENCE instructions)
     std::string body;
     std::vector<char> have_l, have_n, have_pub, have_ch;
     std::string opnd(u32 o) {
@@ -59,7 +60,10 @@ struct Gen {
             snprintf(name, sizeof name, "%c%u", nx ? 'n' : 'l', idx);
             if (!have[idx]) {
                 have[idx] = 1;
-                if (idx < C) appendf(body, "    const u64 %s = p.trace_lde[%uull * p.L + %s];\n", name, idx, nx ? "sn" : "s");
+                if (fenced) {
+                    if (idx < C) appendf(body, "    const u64 %s = %s[%uull * Lq];\n", name, nx ? "tn" : "tp", idx);
+                    else appendf(body, "    const u64 %s = %s[%uull * Lq];\n", name, nx ? "an" : "ap_", idx - C);
+                } else if (idx < C) appendf(body, "    const u64 %s = p.trace_lde[%uull * p.L + %s];\n", name, idx, nx ? "sn" : "s");
                 else appendf(body, "    const u64 %s = p.aux_lde[%uull * p.L + %s];\n", name, idx - C, nx ? "sn" : "s");
             }
             return name;
@@ -86,6 +90,7 @@ struct Gen {
 // accesses per chunk.
 #define JIT_CHUNK_MIN 1536u
 #define JIT_CHUNK 256u
+#define QJIT_FENCE 48u
 static std::string generate_chunked(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname, bool standalone) {
     std::string s;
     if (standalone) {
@@ -150,10 +155,15 @@ static std::string generate_chunked(const zk_air *air, u32 C, u32 A, u32 nch, u3
 
 std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname = "quotient_jit", bool standalone = true) {
     if (air->n_instrs >= JIT_CHUNK_MIN) return generate_chunked(air, C, A, nch, rate_bits, kname, standalone);
-    Gen g; g.air = air; g.C = C; g.A = A;
+    Gen g; g.air = air; g.C = C; g.A = A; g.fenced = true;
     g.have_l.assign(C + A, 0); g.have_n.assign(C + A, 0); g.have_pub.assign(air->n_public_inputs + 1, 0);
     for (u32 pc = 0; pc < air->n_instrs; pc++) {
         const zk_instr &in = air->instrs[pc];
+        // as in the gate kernels of the Plonk half: every QJIT_FENCE instructions the column base pointers pass through an empty asm and
+        // an undecidable never-taken branch ends the basic block, so that hipcc cannot pull every column load to the top of the kernel
+        // (93 + 40 columns, local and next rows: 163 SGPRs spilled to VGPR lanes for the hoisted offsets before, 22 now)
+        if (pc && pc % QJIT_FENCE == 0)
+            appendf(g.body, "    asm volatile(\"\" : \"+v\"(tp), \"+v\"(tn), \"+v\"(ap_), \"+v\"(an));\n    if (p.redo_cap == 0x7FFF0000u + %uu) return;\n", pc);
         std::string a = g.opnd(in.a);
         if (in.op <= ZK_OP_MUL) {
             std::string b = g.opnd(in.b);
@@ -182,6 +192,7 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, co
     // an atomic at the very end of the kernel and had a fix-up kernel redo them: that variant ended in sporadic GPU memory faults
     // that were never understood)
     s += "    auto eval = [&](auto &g) {\n";
+    s += "    const u64 *tp = p.trace_lde + s, *tn = p.trace_lde + sn, *ap_ = p.aux_lde + s, *an = p.aux_lde + sn;\n    const u64 Lq = p.L;\n";
     s += "    const u64 x = g.mul(p.xA[i & 2047], p.xB[i >> 11]);\n    const u64 z_last = gl_sub(x, p.last_inv);\n";
     s += "    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];\n";
     for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = 0; const u64 al%u = p.alphas[%u];\n", j, j, j);
@@ -531,7 +542,7 @@ static int32_t jit_compile_cached(zk_ctx *ctx, const std::string &base_key, bool
     if (!may_compile) { k = JitKernel(); return ZK_OK; }
     std::string disk_key = base_key;
     {
-        const u64 ver[2] = {4 /* generator version */, fnv1a(GL64_SRC)};
+        const u64 ver[2] = {5 /* generator version */, fnv1a(GL64_SRC)};
         disk_key.append((const char *)ver, sizeof ver);
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) disk_key.append(pr.gcnArchName);
