@@ -261,6 +261,17 @@ int32_t zk_ntt_dif(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_
                    int inverse, const TwoLevel *pre, u64 post_const, int canon_in) {
     if (k < 0 || k > 30 || n_cols <= 0) return ctx->fail(ZK_ERR_INVALID_ARG, "ntt_dif: bad size");
     int w[4], np; digit_widths(k, w, &np);
+    // experiment switch (VERDICT r2 #3b): both passes of a column GROUP back to back, so that the second pass finds the first one's output in
+    // the 256 MiB Infinity Cache.  Off by default: the passes are bound by instruction issue, not by HBM.
+    static const int col_group = getenv("ZK_NTT_COL_GROUP") ? atoi(getenv("ZK_NTT_COL_GROUP")) : 0;
+    if (col_group > 0 && np > 1 && n_cols > col_group) {
+        for (int c0 = 0; c0 < n_cols; c0 += col_group) {
+            int32_t rc = zk_ntt_dif(ctx, in + (size_t)c0 * in_stride, in_stride, out + (size_t)c0 * out_stride, out_stride, k, n_cols - c0 < col_group ? n_cols - c0 : col_group,
+                                    inverse, pre, post_const, canon_in);
+            if (rc) return rc;
+        }
+        return ZK_OK;
+    }
     int S = k;
     for (int i = 0; i < np; i++) {
         S -= w[i];
@@ -285,6 +296,15 @@ int32_t zk_ntt_dit(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_
     if (k < 0 || k > 30 || n_cols <= 0) return ctx->fail(ZK_ERR_INVALID_ARG, "ntt_dit: bad size");
     int w[4], np; digit_widths(k, w, &np);
     if (permute_out && np > 1 && !tmp) return ctx->fail(ZK_ERR_INVALID_ARG, "ntt_dit: permuted output needs a scratch buffer");
+    static const int col_group = getenv("ZK_NTT_COL_GROUP") ? atoi(getenv("ZK_NTT_COL_GROUP")) : 0;      // see zk_ntt_dif
+    if (col_group > 0 && np > 1 && n_cols > col_group) {
+        for (int c0 = 0; c0 < n_cols; c0 += col_group) {
+            int32_t rc = zk_ntt_dit(ctx, in + (size_t)c0 * in_stride, in_stride, out + (size_t)c0 * out_stride, out_stride, k, n_cols - c0 < col_group ? n_cols - c0 : col_group,
+                                    inverse, pre, post, permute_out, tmp ? tmp + (size_t)c0 * tmp_stride : nullptr, tmp_stride);
+            if (rc) return rc;
+        }
+        return ZK_OK;
+    }
     // DIT processes the lowest position digit first; use the reversed width order so the last (TILE) pass is the widest-stride one
     int S = 0;
     for (int i = 0; i < np; i++) {
