@@ -257,19 +257,19 @@ class SyntheticRecursion:
         return ctx.poseidon(st[None, :])[0][:4]
 
     def witness(self, ctx, kind, key, degree_bits, pih):
-        """The circuit's witness for THIS proof: the calling worker's own copy of the stand-in witness in pinned host memory (one
+        """The circuit's witness for THIS proof: the proving context's own copy of the stand-in witness in pinned host memory (one
         asynchronous upload at PCIe rate inside zk_prove_plonk, as for a trace from zk_host_alloc), PublicInputGate cells rewritten
         in place.  Upstream generates the witness of every proof on the CPU (plonky2::iop::generator) -- not reproduced here."""
-        import threading
         from . import lib as zl, ops
         circ, wires = self.circuit(kind, key, degree_bits)
-        k = (threading.get_ident(), ctx.device, kind, key, degree_bits)
-        buf = self._pinned.get(k)
+        k = (id(ctx), kind, key, degree_bits)                  # one copy per context: a context serves one proof at a time
+        ent = self._pinned.get(k)
+        buf = ent[1] if ent is not None and ent[0] is ctx else None
         if buf is None:
             owner = ops.P_STATE.state_ctx() if ops.P_STATE is not None and ops.P_STATE.device == ctx.device else ctx
             buf = zl.pinned_empty(owner, wires.shape)
             buf[...] = wires
-            self._pinned[k] = buf
+            self._pinned[k] = (ctx, buf)
         for i, col in enumerate(circ.pi_wires):
             buf[col, 0] = np.uint64(int(pih[i]))
         return buf

@@ -80,6 +80,10 @@ def test_txproof_is_the_whole_prove_root(orc):
         assert set(timing) == {"stark_s", "shrink_s", "root_s"}
         out = ops.TxProof().execute(ops.GenerationInputs(tabs))
         assert out.kind == "Txn" and (out.proof == ref_root).all() and len(out.public_values) == 3
+        st.chain_streams = 3                                  # the three (independent) shrink chains side by side: the same proofs
+        root3, _, all3 = ops.prove_root(ops.GenerationInputs(tabs))
+        assert (root3 == ref_root).all() and (all3 == ref_all).all()
+        st.chain_streams = 1
         # a size no circuits were built for is fatal, as upstream's "Missing preprocessed circuits"
         st.recursion = plonk.SyntheticRecursion(size_shift=-6, threshold=6, seed=2, degree_bits_ranges=[(8, 9)] * 3)
         with pytest.raises(ops.FatalError, match="Missing preprocessed circuits for table 0 with size 7"):

@@ -17,11 +17,12 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--top", type=int, default=14)
 ap.add_argument("--jit", action="store_true", help="compile the constraint kernels of the seven tables first (minutes for the wide ones)")
 ap.add_argument("--size-shift", type=int, default=0)
+ap.add_argument("--chain-streams", type=int, default=3, help="shrink chains of one transaction proved side by side by its worker")
 args = ap.parse_args()
 
 t0 = time.time()
 rec = plonk.SyntheticRecursion(size_shift=args.size_shift)
-st = ops.set_prover_state_from_config(0, recursion=rec)
+st = ops.set_prover_state_from_config(0, recursion=rec, chain_streams=args.chain_streams)
 
 
 def unit(ctx):
