@@ -127,12 +127,7 @@ int32_t zk_batch_commit_dev(zk_ctx *ctx, const u64 *d_cols, uint32_t log_n, uint
     }
     // lde(rate_bits).coset_fft(g): the size-L transform of zero-padded coefficients splits into 2^rate_bits size-n
     // transforms on the cosets g*w_L^par; output half bitrev(par) of the bit-reversed LDE.
-    for (u32 par = 0; rc == ZK_OK && par < (1u << rate_bits); par++) {
-        u64 shift = gl_mul(GL_GEN, gl_pow(gl_root(log_n + rate_bits), par));
-        TwoLevel pre = zk_scale_table(ctx, shift, 1, log_n);
-        u32 half = bitrev_u32(par, rate_bits);
-        rc = zk_ntt_dit(ctx, b->coeffs, n, b->lde + (size_t)half * n, L, log_n, n_cols, 0, &pre, nullptr, 1, tmp, n);
-    }
+    if (rc == ZK_OK) rc = zk_ntt_lde(ctx, b->coeffs, n, b->lde, L, log_n, n_cols, rate_bits, tmp, n);
     if (rc == ZK_OK) rc = zk_hash_leaves_colmajor(ctx, b->lde, L, n_cols, L, b->levels);
     if (rc == ZK_OK) rc = zk_merkle_levels(ctx, b->levels, L, cap_height);
     ctx->release(tmp);

@@ -225,7 +225,11 @@ TwoLevel zk_scale_table(zk_ctx *ctx, u64 base, u64 premul, int log_count) {
 }
 
 // ------------------------------------------------------------------ host: pass schedules
+// k <= 12: ONE pass over whole rows (the register-radix kernel does 2^11 / 2^12 points as three radix-16 phases; ZK_NTT_ROW_W=10 brings
+// back the two-pass split for an A/B run); beyond that, passes of at most 10 bits.
 static void digit_widths(int k, int *w, int *np) {
+    static const int row_w = getenv("ZK_NTT_ROW_W") ? atoi(getenv("ZK_NTT_ROW_W")) : 12;
+    if (k > NTT_MAX_W && k <= row_w && k <= 12) { w[0] = k; *np = 1; return; }
     int passes = (k + NTT_MAX_W - 1) / NTT_MAX_W;
     if (passes < 1) passes = 1;
     int base = k / passes, extra = k % passes;
@@ -328,6 +332,59 @@ int32_t zk_ntt_dit(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_
         S += W;
     }
     return ZK_OK;
+}
+
+// lde(rate_bits).coset_fft(g) of bit-reversed coefficient columns: the size-L transform of zero-padded coefficients is 2^rate_bits size-n
+// transforms on the cosets g * w_L^par, coset par filling block bitrev(par) of every (bit-reversed) LDE column.  Small batches -- the
+// Plonk half's circuits, the narrow tables -- run ALL cosets in one launch per pass (virtual columns, ntt_fast_kernel<.., CS>): a single
+// coset of 135 wires x 2^12 rows is 67 workgroups on 256 compute units, and an LDE with rate_bits 3 used to be 16 such launches.
+// tmp (n_cols x n, stride tmp_stride): scratch of the coset-by-coset path; the merged path brings its own.
+int32_t zk_ntt_lde(zk_ctx *ctx, const u64 *coeffs, size_t in_stride, u64 *lde, size_t out_stride, int log_n, int n_cols, int rate_bits,
+                   u64 *tmp, size_t tmp_stride) {
+    if (log_n < 0 || log_n > 30 || n_cols <= 0 || rate_bits < 0 || rate_bits > 4) return ctx->fail(ZK_ERR_INVALID_ARG, "ntt_lde: bad size");
+    const size_t n = (size_t)1 << log_n;
+    const u32 P = 1u << rate_bits;
+    const u64 wL = gl_root(log_n + rate_bits);
+    int w[4], np; digit_widths(log_n, w, &np);
+    static const int merge = getenv("ZK_NTT_COSET_MERGE") ? atoi(getenv("ZK_NTT_COSET_MERGE")) : 1;
+    bool merged = merge && rate_bits >= 1 && log_n >= 4 && log_n <= 20 && np <= 2 && !getenv("ZK_NTT_SLOW") &&
+                  (n >> 13) * (size_t)n_cols < 4096;                   // a launch per coset already fills the chip beyond this
+    if (merged && np == 2 && w[1] < 13 - w[0]) merged = false;          // the TILE pass would not take the register-radix kernel
+    if (merged) {
+        u64 *mid = nullptr;
+        const size_t mid_stride = n * P;
+        if (np > 1) { mid = (u64 *)ctx->alloc(mid_stride * (size_t)n_cols * sizeof(u64)); if (!mid) return ZK_ERR_OOM; }
+        int S = 0;
+        int32_t rc = ZK_OK;
+        for (int i = 0; i < np && rc == ZK_OK; i++) {
+            const int W = w[np - 1 - i];
+            const bool last = i == np - 1, row = S == 0;
+            PassParams p = {};
+            p.in = i == 0 ? coeffs : mid; p.in_stride = i == 0 ? in_stride : mid_stride; p.in_sub = i == 0 ? 0 : n;
+            p.out = last ? lde : mid; p.out_stride = last ? out_stride : mid_stride; p.out_sub = n;
+            p.k = log_n; p.W = W; p.S = S; p.n_cols = n_cols; p.cs_bits = rate_bits;
+            p.tw_digit = zk_digit_twiddles(ctx, W, 0); p.tw_full = zk_full_digit_table(ctx, W, 0);
+            if (S > 0) { TwoLevel t = zk_root_table(ctx, W + S, 0); p.twA = t.A; p.twB = t.B; }
+            if (i == 0) {
+                for (u32 h = 0; h < P; h++) {
+                    TwoLevel pre = zk_scale_table(ctx, gl_mul(GL_GEN, gl_pow(wL, bitrev_u32(h, rate_bits))), 1, log_n);
+                    p.cs_preA[h] = pre.A; p.cs_preB[h] = pre.B;
+                }
+                p.pre_bitrev = 1;
+            }
+            p.permute_out = last ? 1 : 0;
+            if (!zk_ntt_fast_pass(ctx, p, true, row, row ? "ntt_dit_row" : "ntt_dit_tile")) rc = ctx->fail(ZK_ERR_OOM, "ntt_lde: merged pass not launched");
+            S += W;
+        }
+        if (mid) ctx->release(mid);
+        return rc;
+    }
+    int32_t rc = ZK_OK;
+    for (u32 par = 0; rc == ZK_OK && par < P; par++) {
+        TwoLevel pre = zk_scale_table(ctx, gl_mul(GL_GEN, gl_pow(wL, par)), 1, log_n);
+        rc = zk_ntt_dit(ctx, coeffs, in_stride, lde + (size_t)bitrev_u32(par, rate_bits) * n, out_stride, log_n, n_cols, 0, &pre, nullptr, 1, tmp, tmp_stride);
+    }
+    return rc;
 }
 
 int32_t zk_bitrev_copy(zk_ctx *ctx, const u64 *in, size_t in_stride, u64 *out, size_t out_stride, int k, int n_cols) {

@@ -22,6 +22,11 @@ struct PassParams {
     const u64 *store_tab;           // multiply the element stored to position pos by store_tab[pos]  (or NULL)
     int force_redo;                 // test hook: take the exact-redo branch in every workgroup (ctx->force_redo)
     int col_fast;                   // blockIdx -> (tile, column) with the column fastest, so table slices stay in L2
+    // coset-merged LDE (DIT, register-radix kernel only): cs_bits > 0 makes the launch cover n_cols << cs_bits virtual columns;
+    // virtual column v = (column v >> cs_bits, slot v & mask) sits at column * stride + slot * sub; its factors at load_tab + slot * tab_sub
+    int cs_bits;
+    size_t in_sub, out_sub, tab_sub;
+    const u64 *cs_preA[16], *cs_preB[16];   // host side only: the input scale table of every slot (zk_ntt_fast_pass folds them into load_tab)
 };
 
 __device__ __forceinline__ u64 tab2(const u64 *A, const u64 *B, u32 x) { return gl_mul(A[x & 2047], B[x >> 11]); }

@@ -317,11 +317,7 @@ int32_t zk_fri_prove_dev(zk_ctx *ctx, const zk_stark_config &cfg, DevChallenger 
     cp.nch = nch; cp.n = n; cp.apow = d_apow; cp.P = P;
     if (n <= ((size_t)1 << 16)) ZK_LAUNCH(ctx, "fri_combine", fri_combine_split_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, cp);
     else ZK_LAUNCH(ctx, "fri_combine", fri_combine_kernel, g1(n), dim3(256), 0, cp);
-    for (u32 par = 0; rc == ZK_OK && par < (1u << rate_bits); par++) {
-        u64 shift = gl_mul(GL_GEN, gl_pow(gl_root(lgL), par));
-        TwoLevel pre = zk_scale_table(ctx, shift, 1, log_n);
-        rc = zk_ntt_dit(ctx, P, n, Pval + (size_t)bitrev_u32(par, rate_bits) * n, L, log_n, 2 * nb, 0, &pre, nullptr, 1, tmp, n);
-    }
+    if (rc == ZK_OK) rc = zk_ntt_lde(ctx, P, n, Pval, L, log_n, 2 * nb, rate_bits, tmp, n);
     if (rc) return rc;
     QuotParams qp = {};
     qp.Pval = Pval; qp.L = L; qp.lgL = lgL; qp.nb = nb;
@@ -558,11 +554,7 @@ int32_t zk_fri_final_values_dev(zk_ctx *ctx, const zk_stark_config &cfg, const u
     for (u32 b = 0; rc == ZK_OK && b < nb; b++) rc = zk_eval_cols_at(ctx, P + (size_t)2 * b * n, n, log_n, 2, d_pts + 2 * b, d_ev + 4 * b);
     if (rc) return rc;
     ZK_LAUNCH(ctx, "fri_join_evals", fri_join_evals_kernel, dim3(1), dim3(64), 0, (const u64 *)d_ev, nb, d_y);
-    for (u32 par = 0; rc == ZK_OK && par < (1u << rate_bits); par++) {
-        u64 shift = gl_mul(GL_GEN, gl_pow(gl_root(lgL), par));
-        TwoLevel pre = zk_scale_table(ctx, shift, 1, log_n);
-        rc = zk_ntt_dit(ctx, P, n, Pval + (size_t)bitrev_u32(par, rate_bits) * n, L, log_n, 2 * nb, 0, &pre, nullptr, 1, tmp, n);
-    }
+    if (rc == ZK_OK) rc = zk_ntt_lde(ctx, P, n, Pval, L, log_n, 2 * nb, rate_bits, tmp, n);
     if (rc) return rc;
     QuotGenParams qp = {};
     qp.Pval = Pval; qp.L = L; qp.lgL = lgL; qp.nb = nb; qp.err = ctx->d_err;

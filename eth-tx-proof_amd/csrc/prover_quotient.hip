@@ -183,11 +183,7 @@ int32_t zk_lagrange_table(zk_ctx *ctx, u32 log_n, u32 rate_bits, u64 **out) {
     hipMemsetAsync(ind, 0, 2 * n * sizeof(u64), ctx->stream);
     ZK_LAUNCH(ctx, "set_indicator", set_indicator_kernel, dim3(1), dim3(1), 0, ind, n);
     int32_t rc = zk_ntt_dif(ctx, ind, n, co, n, log_n, 2, 1, nullptr, gl_inv((u64)n % GL_P), 0);
-    for (u32 par = 0; rc == ZK_OK && par < (1u << rate_bits); par++) {
-        u64 shift = gl_mul(GL_GEN, gl_pow(gl_root(log_n + rate_bits), par));
-        TwoLevel pre = zk_scale_table(ctx, shift, 1, log_n);
-        rc = zk_ntt_dit(ctx, co, n, lde + (size_t)bitrev_u32(par, rate_bits) * n, L, log_n, 2, 0, &pre, nullptr, 1, tmp, n);
-    }
+    if (rc == ZK_OK) rc = zk_ntt_lde(ctx, co, n, lde, L, log_n, 2, rate_bits, tmp, n);
     ctx->release(ind); ctx->release(co); ctx->release(tmp);
     if (rc != ZK_OK) { ctx->release(lde); return rc; }
     ctx->lagrange_tab[key] = lde;
