@@ -226,7 +226,7 @@ static const char PLK_PARAMS_SRC[] =
 #define PLK_SEG 768u
 #define PLK_SEG_SLACK 192u
 #define PLK_FENCE 64u
-#define PLK_GEN_VERSION 6u
+#define PLK_GEN_VERSION 7u
 
 // where the program is cut and which registers cross each cut
 struct PlkPlan { std::vector<u32> cut; std::vector<std::vector<u32>> live; u32 max_live = 0; };   // segment k = [cut[k], cut[k+1]); live[k]: registers alive at cut[k+1]
@@ -293,6 +293,54 @@ struct PGen {
     }
 };
 
+static bool plonk_small_const(const zk_air *air, u32 o, u64 *v) {
+    if ((o >> 24) != ZK_OPND_CONST) return false;
+    *v = gl_canon(air->constants[o & 0xFFFFFF]);
+    return *v < (1ull << 16);
+}
+// [pc, end of run) if instructions pc.. are  MUL d, x0, c0;  (MUL t, xi, ci;  ADD d, d, t) x (n - 1)  with n >= 3 small constants whose sum
+// stays below 2^31, no xi reading d or a temporary, and every temporary t dead behind the run (overwritten before it is read); else 0
+static u32 plonk_dot_run(const zk_air *air, u32 pc, u32 end) {
+    static const int on = getenv("ZK_PLONK_DOT_FUSE") ? atoi(getenv("ZK_PLONK_DOT_FUSE")) : 1;
+    if (!on) return 0;
+    const zk_instr &h = air->instrs[pc];
+    if (h.op != ZK_OP_MUL) return 0;
+    u64 c, sum = 0;
+    const bool hb = plonk_small_const(air, h.b, &c);
+    if (!hb && !plonk_small_const(air, h.a, &c)) return 0;
+    sum = c;
+    const u32 d = h.dst & 0xFFFFFF, dreg = ((u32)ZK_OPND_REG << 24) | d;
+    std::vector<u32> temps;
+    u32 q = pc + 1, n = 1;
+    while (q + 1 < end) {
+        const zk_instr &m = air->instrs[q], &a = air->instrs[q + 1];
+        if (m.op != ZK_OP_MUL || a.op != ZK_OP_ADD) break;
+        const bool mb = plonk_small_const(air, m.b, &c);
+        if (!mb && !plonk_small_const(air, m.a, &c)) break;
+        const u32 t = m.dst & 0xFFFFFF, treg = ((u32)ZK_OPND_REG << 24) | t, x = mb ? m.a : m.b;
+        if (t == d || x == dreg || x == treg) break;
+        bool x_is_temp = false;
+        for (u32 tt : temps) x_is_temp |= x == (((u32)ZK_OPND_REG << 24) | tt);
+        if (x_is_temp) break;
+        if ((a.dst & 0xFFFFFF) != d || !((a.a == dreg && a.b == treg) || (a.a == treg && a.b == dreg))) break;
+        if (sum + c >= (1ull << 31)) break;
+        sum += c; temps.push_back(t); n++; q += 2;
+    }
+    if (n < 3) return 0;
+    for (u32 t : temps) {
+        const u32 treg = ((u32)ZK_OPND_REG << 24) | t;
+        if ((hb ? h.a : h.b) == treg) return 0;
+        bool dead = true;                                     // dead unless read before the next write
+        for (u32 r = q; r < air->n_instrs; r++) {
+            const zk_instr &in = air->instrs[r];
+            if (in.a == treg || (in.op <= ZK_OP_MUL && in.b == treg)) { dead = false; break; }
+            if (in.op <= ZK_OP_MUL && (in.dst & 0xFFFFFF) == t) break;
+        }
+        if (!dead) return 0;
+    }
+    return q;
+}
+
 // kernels kname_0 .. kname_{K-1}; *n_kernels, *n_state (state slots per point: nch accumulators + the most registers alive at a cut)
 static std::string generate_plonk(const zk_air *air, u32 W, u32 NC, u32 nch, u32 rate_bits, const char *kname, bool standalone, u32 *n_kernels, u32 *n_state) {
     std::string s;
@@ -328,6 +376,7 @@ static std::string generate_plonk(const zk_air *air, u32 W, u32 NC, u32 nch, u32
     for (u32 k = 0; k < K; k++) {
         PGen g; g.air = air; g.W = W;
         g.have_l.assign(W + NC, 0); g.have_pub.assign(4, 0);
+        u32 next_fence = PLK_FENCE;
         for (u32 pc = pl.cut[k]; pc < pl.cut[k + 1]; pc++) {
             const zk_instr &in = air->instrs[pc];
             // every PLK_FENCE instructions the column base pointers pass through an empty asm: loads behind it cannot be hoisted above it.
@@ -335,8 +384,28 @@ static std::string generate_plonk(const zk_air *air, u32 W, u32 NC, u32 nch, u32
             // scratch; a gate kernel with scratch on several streams at once ended in a GPU memory fault.
             // ... and a branch the compiler cannot decide (never taken: n_regs is a small number) ends the basic block there, so that the
             // scheduler does not pull the materialisation of hundreds of 64-bit constants (PoseidonGate's partial rounds) to the top either.
-            if (pc > pl.cut[k] && (pc - pl.cut[k]) % PLK_FENCE == 0)
+            if (pc - pl.cut[k] >= next_fence && (next_fence += PLK_FENCE, true))      // (a fused run below may have stepped over the multiple itself)
                 appendf(g.body, "    asm volatile(\"\" : \"+v\"(wp), \"+v\"(cp), \"+s\"(gc));\n    if (p.n_regs == 0x7FFF0000u + %uu) return;\n", pc);
+            // A run  d = x0 c0;  t = x1 c1;  d = d + t;  t = x2 c2;  d = d + t; ...  with small constants (an MDS row of PoseidonGate: 96 rows of
+            // 12 terms, a third of the gate set's instructions) becomes ONE dot product with deferred reduction (glx::dot_acc / dot_fold).
+            {
+                const u32 run_end = plonk_dot_run(air, pc, pl.cut[k + 1]);
+                if (run_end) {
+                    const u32 d = air->instrs[pc].dst & 0xFFFFFF;
+                    std::vector<std::pair<std::string, u64>> terms;
+                    for (u32 q = pc; q < run_end; q += (q == pc ? 1 : 2)) {
+                        const zk_instr &m = air->instrs[q];
+                        u64 cv; const bool cb = plonk_small_const(air, m.b, &cv);
+                        if (!cb) plonk_small_const(air, m.a, &cv);
+                        terms.emplace_back(g.opnd(cb ? m.a : m.b), cv);
+                    }
+                    g.body += "    { u64 al = 0, ah = 0;";
+                    for (auto &t : terms) appendf(g.body, " g.dot_acc(al, ah, %s, %lluu);", t.first.c_str(), (unsigned long long)t.second);
+                    appendf(g.body, " r%u = g.dot_fold(al, ah); }\n", d);
+                    pc = run_end - 1;
+                    continue;
+                }
+            }
             std::string a = g.opnd(in.a);
             if (in.op <= ZK_OP_MUL) {
                 std::string b = g.opnd(in.b);

@@ -22,12 +22,16 @@ else:
 st = zl.PlonkState(ctx, cfg, circ)
 d = ctx.dev_alloc(wires.nbytes); ctx.upload(d, wires)
 p = zl.prove_plonk(st, d, pub).copy()
+t0 = time.time()
+for _ in range(reps):
+    zl.prove_plonk(st, d, pub)
+print("profiler off: %.2f ms per proof" % ((time.time() - t0) / reps * 1e3))
 ctx.profile(True); ctx.profile_reset()
 t0 = time.time()
 for _ in range(reps):
     zl.prove_plonk(st, d, pub)
 dt = (time.time() - t0) / reps
-print("plonk proof 2^%d rows x 135 wires, %s gates: %.2f ms on the GPU (device-resident witness), %d words" % (k, "toy" if toy else "recursion-shaped", dt * 1e3, p.size))
+print("plonk proof 2^%d rows x 135 wires, %s gates: %.2f ms on the GPU with the hipEvent profiler on (device-resident witness), %d words" % (k, "toy" if toy else "recursion-shaped", dt * 1e3, p.size))
 for name, (l, ms) in sorted(ctx.profile_report().items(), key=lambda kv: -kv[1][1])[:16]:
     print("  %-28s %5d launches %8.3f ms/proof" % (name, l // reps, ms / reps))
 if not os.environ.get("NO_ORACLE"):

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_pr
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o pr -- python3 $R/bench.py --workload prove_root --steps 6 > $OUT/bench.json 2> $OUT/bench.err || { tail -3 $OUT/bench.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o pr -- python3 $R/bench.py --workload prove_root --steps 6 ${PR_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err || { tail -3 $OUT/bench.err; exit 1; }
 cd $R
 python3 - <<'PY'
 import csv, json, glob
