@@ -91,6 +91,98 @@ __global__ void eval_reduce_kernel(const u64 *partial, int LB, int n_cols, u64 *
     out[2 * c] = a; out[2 * c + 1] = b;
 }
 
+// Several evaluations of one proof in three launches: every column block of every job in ONE eval_cols launch, the power tables built once
+// per distinct point (OpeningSet::new / StarkOpeningSet::new are six column blocks at two points: eighteen launches one by one).
+struct EvalMulti {
+    u32 n_jobs, n_points;
+    u32 col0[ZK_EVAL_MAX_JOBS + 1];                      // first column (of the concatenation) of every job
+    u32 point_of[ZK_EVAL_MAX_JOBS];
+    const u64 *coeffs[ZK_EVAL_MAX_JOBS]; size_t stride[ZK_EVAL_MAX_JOBS];
+    u64 *out[ZK_EVAL_MAX_JOBS];
+    const u64 *points[ZK_EVAL_MAX_JOBS];
+};
+__global__ void eval_tables_multi_kernel(EvalMulti m, EvalGeom g, u32 ntab, u64 *tab) {
+    const u32 pt = blockIdx.y, id = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nT = 1u << g.LT, nI = 1u << g.LI, nB = 1u << g.LB;
+    if (id >= nT + nI + nB) return;
+    const u64 *point = m.points[pt];
+    gl2 z = gl2_make(gl_canon(point[0]), gl_canon(point[1]));
+    gl2 base; u32 e;
+    if (id < nT) { base = z; for (int s = 0; s < g.k - g.LT; s++) base = gl2_mul(base, base); e = bitrev_u32(id, g.LT); }
+    else if (id < nT + nI) { base = z; for (int s = 0; s < g.LB; s++) base = gl2_mul(base, base); e = bitrev_u32(id - nT, g.LI); }
+    else { base = z; e = bitrev_u32(id - nT - nI, g.LB); }
+    gl2 v = ext_pow_bits(base, e);
+    tab[2 * ((size_t)pt * ntab + id)] = v.a; tab[2 * ((size_t)pt * ntab + id) + 1] = v.b;
+}
+__global__ __launch_bounds__(256) void eval_cols_multi_kernel(EvalMulti m, EvalGeom g, u32 ntab, const u64 *__restrict__ tabs, u64 *__restrict__ partial) {
+    __shared__ u64 red[2 * 256];
+    const u32 t = threadIdx.x, B = blockIdx.x, vcol = blockIdx.y;
+    u32 job = 0;
+    while (job + 1 < m.n_jobs && vcol >= m.col0[job + 1]) job++;
+    const u32 col = vcol - m.col0[job];
+    const u64 *tab = tabs + 2 * (size_t)m.point_of[job] * ntab;
+    const u32 nT = 1u << g.LT, nI = 1u << g.LI;
+    const u64 *zi = tab + 2 * nT, *zb = tab + 2 * (nT + nI);
+    gl2 acc = gl2_make(0, 0);
+    if (t < nT) {
+        const u64 *p = m.coeffs[job] + (size_t)col * m.stride[job] + ((size_t)B << (g.LT + g.LI)) + t;
+        for (u32 i = 0; i < nI; i++) {
+            u64 c = p[(size_t)i << g.LT];
+            acc.a = gl_add(acc.a, gl_mul(c, zi[2 * i]));
+            acc.b = gl_add(acc.b, gl_mul(c, zi[2 * i + 1]));
+        }
+        acc = gl2_mul(acc, gl2_make(tab[2 * t], tab[2 * t + 1]));
+    }
+    red[2 * t] = acc.a; red[2 * t + 1] = acc.b;
+    __syncthreads();
+    for (u32 s = 128; s > 0; s >>= 1) {
+        if (t < s) { red[2 * t] = gl_add(red[2 * t], red[2 * (t + s)]); red[2 * t + 1] = gl_add(red[2 * t + 1], red[2 * (t + s) + 1]); }
+        __syncthreads();
+    }
+    if (t == 0) {
+        gl2 r = gl2_mul(gl2_make(red[0], red[1]), gl2_make(zb[2 * B], zb[2 * B + 1]));
+        size_t o = ((size_t)vcol << g.LB) + B;
+        partial[2 * o] = r.a; partial[2 * o + 1] = r.b;
+    }
+}
+__global__ void eval_reduce_multi_kernel(EvalMulti m, const u64 *partial, int LB, u64 *unused) {
+    const u32 vcol = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vcol >= m.col0[m.n_jobs]) return;
+    u32 job = 0;
+    while (job + 1 < m.n_jobs && vcol >= m.col0[job + 1]) job++;
+    u64 a = 0, b = 0;
+    for (u32 B = 0; B < (1u << LB); B++) { a = gl_add(a, partial[2 * (((size_t)vcol << LB) + B)]); b = gl_add(b, partial[2 * (((size_t)vcol << LB) + B) + 1]); }
+    u64 *out = m.out[job] + 2 * (size_t)(vcol - m.col0[job]);
+    out[0] = a; out[1] = b;
+}
+int32_t zk_eval_cols_multi(zk_ctx *ctx, int k, u32 n_jobs, const zk_eval_job *jobs) {
+    if (n_jobs == 0) return ZK_OK;
+    if (n_jobs > ZK_EVAL_MAX_JOBS) return ctx->fail(ZK_ERR_INVALID_ARG, "eval_cols_multi: too many jobs");
+    EvalMulti m = {};
+    m.n_jobs = n_jobs;
+    u32 total = 0;
+    for (u32 j = 0; j < n_jobs; j++) {
+        m.col0[j] = total; total += jobs[j].n_cols;
+        m.coeffs[j] = jobs[j].coeffs; m.stride[j] = jobs[j].stride; m.out[j] = jobs[j].d_out;
+        u32 pt = 0;
+        while (pt < m.n_points && m.points[pt] != jobs[j].d_point) pt++;
+        if (pt == m.n_points) m.points[m.n_points++] = jobs[j].d_point;
+        m.point_of[j] = pt;
+    }
+    m.col0[n_jobs] = total;
+    if (total == 0) return ZK_OK;
+    EvalGeom g = eval_geom(k);
+    const u32 ntab = (1u << g.LT) + (1u << g.LI) + (1u << g.LB);
+    u64 *tab = (u64 *)ctx->alloc((size_t)ntab * m.n_points * 2 * sizeof(u64));
+    u64 *partial = (u64 *)ctx->alloc(((size_t)total << g.LB) * 2 * sizeof(u64));
+    if (!tab || !partial) return ZK_ERR_OOM;
+    ZK_LAUNCH(ctx, "eval_tables", eval_tables_multi_kernel, dim3((ntab + 255) / 256, m.n_points), dim3(256), 0, m, g, ntab, tab);
+    ZK_LAUNCH(ctx, "eval_cols", eval_cols_multi_kernel, dim3(1u << g.LB, total), dim3(256), 0, m, g, ntab, (const u64 *)tab, partial);
+    ZK_LAUNCH(ctx, "eval_reduce", eval_reduce_multi_kernel, dim3((total + 255) / 256), dim3(256), 0, m, (const u64 *)partial, g.LB, (u64 *)nullptr);
+    ctx->release(tab); ctx->release(partial);
+    return ZK_OK;
+}
+
 int32_t zk_eval_cols_at(zk_ctx *ctx, const u64 *coeffs, size_t stride, int k, int n_cols, const u64 *d_point, u64 *d_out) {
     EvalGeom g = eval_geom(k);
     u32 ntab = (1u << g.LT) + (1u << g.LI) + (1u << g.LB);

@@ -449,6 +449,30 @@ __global__ __launch_bounds__(256) void fri_combine_gen_kernel(CombineGenParams p
     }
     p.P[(size_t)(2 * b) * p.n + pos] = ra; p.P[(size_t)(2 * b + 1) * p.n + pos] = rb;
 }
+// the same for small polynomials: 8 threads share a position, each sums an eighth of the batch's columns, the partial sums meet in LDS
+// (2^12 positions are 16 workgroups of the kernel above, every thread walking ~250 dependent column loads)
+__global__ __launch_bounds__(256) void fri_combine_gen_split_kernel(CombineGenParams p) {
+    __shared__ u64 part[2][8][32];
+    const u32 t = threadIdx.x, lp = t & 31, slice = t >> 5, b = blockIdx.y;
+    const size_t pos = (size_t)blockIdx.x * 32 + lp;
+    const bool live = pos < p.n;
+    const u64 *const *cols = p.cols + p.start[b];
+    const u32 cnt = p.cnt[b], per = (cnt + 7) / 8, lo = slice * per, hi = lo + per < cnt ? lo + per : cnt;
+    u64 ra = 0, rb = 0;
+    if (live) {
+        for (u32 j = lo; j < hi; j++) {
+            const u64 v = cols[j][pos];
+            ra = gl_add(ra, gl_mul(v, p.apow[2 * j])); rb = gl_add(rb, gl_mul(v, p.apow[2 * j + 1]));
+        }
+    }
+    part[0][slice][lp] = ra; part[1][slice][lp] = rb;
+    __syncthreads();
+    if (slice < 2 && live) {
+        u64 acc = part[slice][0][lp];
+        for (int q = 1; q < 8; q++) acc = gl_add(acc, part[slice][q][lp]);
+        p.P[(size_t)(2 * b + slice) * p.n + pos] = acc;
+    }
+}
 // P_b(z_b) from the evaluations of its re and im columns: y = ev_re + X * ev_im, X^2 = 7
 __global__ void fri_join_evals_kernel(const u64 *ev, u32 nb, u64 *y) {
     u32 b = threadIdx.x;
@@ -549,9 +573,14 @@ int32_t zk_fri_final_values_dev(zk_ctx *ctx, const zk_stark_config &cfg, const u
         if (batches[b].d_point) ZK_LAUNCH(ctx, "fri_copy_point", fri_copy_point_kernel, dim3(1), dim3(64), 0, batches[b].d_point, d_pts + 2 * b);
     ZK_LAUNCH(ctx, "fri_alpha_pows", alpha_pows_gen_kernel, g1(gp.cnt + FRI_MAX_BATCHES), dim3(256), 0, d_alpha, gp, d_apow);
     cp.cols = d_cols; cp.n = n; cp.apow = d_apow; cp.P = P;
-    ZK_LAUNCH(ctx, "fri_combine", fri_combine_gen_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, cp);
+    if (n <= ((size_t)1 << 16)) ZK_LAUNCH(ctx, "fri_combine", fri_combine_gen_split_kernel, dim3((unsigned)((n + 31) / 32), nb), dim3(256), 0, cp);
+    else ZK_LAUNCH(ctx, "fri_combine", fri_combine_gen_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, cp);
     // P_b(z_b): what divide_by_linear drops as the remainder
-    for (u32 b = 0; rc == ZK_OK && b < nb; b++) rc = zk_eval_cols_at(ctx, P + (size_t)2 * b * n, n, log_n, 2, d_pts + 2 * b, d_ev + 4 * b);
+    {
+        zk_eval_job jobs[FRI_MAX_BATCHES];
+        for (u32 b = 0; b < nb; b++) jobs[b] = {P + (size_t)2 * b * n, n, 2u, d_pts + 2 * b, d_ev + 4 * b};
+        rc = zk_eval_cols_multi(ctx, (int)log_n, nb, jobs);
+    }
     if (rc) return rc;
     ZK_LAUNCH(ctx, "fri_join_evals", fri_join_evals_kernel, dim3(1), dim3(64), 0, (const u64 *)d_ev, nb, d_y);
     if (rc == ZK_OK) rc = zk_ntt_lde(ctx, P, n, Pval, L, log_n, 2 * nb, rate_bits, tmp, n);

@@ -275,16 +275,25 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
 
         // ---- StarkOpeningSet::new: every coefficient polynomial at zeta, trace and aux also at g*zeta, Z columns at 1
         std::unique_ptr<ProfScope> ph_open(new ProfScope(ctx, "phase: construct the opening set"));
-        rc = zk_eval_cols_at(ctx, trace_b[t]->coeffs, n, log_n, C, d_zeta, d_proof + y.fri.o_local);
-        if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, trace_b[t]->coeffs, n, log_n, C, d_zeta + 2, d_proof + y.fri.o_next);
-        if (rc == ZK_OK && A) rc = zk_eval_cols_at(ctx, aux_b[t]->coeffs, n, log_n, A, d_zeta, d_proof + y.fri.o_aux);
-        if (rc == ZK_OK && A) rc = zk_eval_cols_at(ctx, aux_b[t]->coeffs, n, log_n, A, d_zeta + 2, d_proof + y.fri.o_auxn);
-        if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, quot_b[t]->coeffs, n, log_n, Q, d_zeta, d_proof + y.fri.o_q);
-        if (rc == ZK_OK && A) {
-            u64 *zs = (u64 *)ctx->alloc(2 * nch * sizeof(u64));
-            if (!zs) { rc = ZK_ERR_OOM; break; }
-            rc = zk_eval_cols_at(ctx, aux_b[t]->coeffs + (size_t)(A - nch) * n, n, log_n, nch, d_zeta + 4, zs);
-            ZK_LAUNCH(ctx, "take_re", take_re_kernel, dim3(1), dim3(64), 0, (const u64 *)zs, nch, d_proof + y.fri.o_zs);
+        u64 *zs = nullptr;
+        {
+            zk_eval_job jobs[6]; u32 nj = 0;
+            jobs[nj++] = {trace_b[t]->coeffs, n, C, d_zeta, d_proof + y.fri.o_local};
+            jobs[nj++] = {trace_b[t]->coeffs, n, C, d_zeta + 2, d_proof + y.fri.o_next};
+            if (A) {
+                jobs[nj++] = {aux_b[t]->coeffs, n, A, d_zeta, d_proof + y.fri.o_aux};
+                jobs[nj++] = {aux_b[t]->coeffs, n, A, d_zeta + 2, d_proof + y.fri.o_auxn};
+            }
+            jobs[nj++] = {quot_b[t]->coeffs, n, Q, d_zeta, d_proof + y.fri.o_q};
+            if (A) {
+                zs = (u64 *)ctx->alloc(2 * nch * sizeof(u64));
+                if (!zs) { rc = ZK_ERR_OOM; break; }
+                jobs[nj++] = {aux_b[t]->coeffs + (size_t)(A - nch) * n, n, nch, d_zeta + 4, zs};
+            }
+            rc = zk_eval_cols_multi(ctx, (int)log_n, nj, jobs);
+        }
+        if (zs) {
+            if (rc == ZK_OK) ZK_LAUNCH(ctx, "take_re", take_re_kernel, dim3(1), dim3(64), 0, (const u64 *)zs, nch, d_proof + y.fri.o_zs);
             ctx->release(zs);
         }
         ph_open.reset();

@@ -160,6 +160,45 @@ __global__ __launch_bounds__(256) void plonk_perm_rows_kernel(PermParams p) {
         }
     }
 }
+// The same with the chunks of a row spread over the workgroup: 32 rows x 8 slots, slot s takes the (challenge, chunk) pairs s, s + 8, ...
+// (a 2^12-row circuit is 16 workgroups of the row-per-thread kernel, each thread walking 2 x 80 dependent loads: 146 us of pure
+// latency; here a thread walks at most 3 chunks of 8 wires and one wave per workgroup does the 64 inversions: same values, ~25 us).
+// LDS: numerator and denominator products [pair][row].  nch * nchunks <= 64.
+__global__ __launch_bounds__(256) void plonk_perm_rows_split_kernel(PermParams p) {
+    __shared__ u64 shN[64][32], shD[64][32];
+    const u32 rl = threadIdx.x & 31, slot = threadIdx.x >> 5;
+    const size_t r = (size_t)blockIdx.x * 32 + rl;
+    const bool live = r < p.n;
+    const u32 G = p.nch * p.nchunks;
+    if (live) {
+        const u64 x = gl_mul(p.xA[r & 2047], p.xB[r >> 11]);
+        for (u32 g = slot; g < G; g += 8) {
+            const u32 ci = g / p.nchunks, c = g % p.nchunks;
+            const u64 beta = p.bg[ci], gamma = p.bg[p.nch + ci];
+            u64 num = 1, den = 1;
+            for (u32 t = 0; t < p.qdf; t++) {
+                const u32 j = c * p.qdf + t;
+                const u64 w = p.wires[(size_t)j * p.n + r];
+                num = gl_mul(num, gl_add(gl_add(w, gl_mul(beta, gl_mul(p.kis[j], x))), gamma));
+                den = gl_mul(den, gl_add(gl_add(w, gl_mul(beta, p.sigmas[(size_t)j * p.n + r])), gamma));
+            }
+            shN[g][rl] = num; shD[g][rl] = den;
+        }
+    }
+    __syncthreads();
+    if (!live || slot >= p.nch) return;
+    const u32 ci = slot, g0 = ci * p.nchunks;
+    u64 dall = 1;
+    for (u32 c = 0; c < p.nchunks; c++) dall = gl_mul(dall, shD[g0 + c][rl]);
+    if (dall == 0) { atomicCAS((unsigned long long *)p.err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_ZERO_INVERSE); }
+    u64 dinv = plk_inv(dall);                            // = 1 / (D_0 .. D_{last})
+    u64 a = 1;
+    for (u32 c = 0; c < p.nchunks; c++) { a = gl_mul(a, shN[g0 + c][rl]); shN[g0 + c][rl] = a; }       // prefix numerators (this thread's own cells)
+    for (u32 c = p.nchunks; c-- > 0;) {
+        p.q[((size_t)ci * p.nchunks + c) * p.n + r] = gl_mul(shN[g0 + c][rl], dinv);
+        dinv = gl_mul(dinv, shD[g0 + c][rl]);
+    }
+}
 // the same for any number of chunks (more than PLK_MAX_CHUNKS: routed-wire counts beyond 16 x quotient_degree_factor): prefix numerators
 // go to q, the chunk denominators to a scratch column block `den` [chunk][row], both re-read on the way down
 __global__ __launch_bounds__(256) void plonk_perm_rows_wide_kernel(PermParams p, u64 *den) {
@@ -460,7 +499,10 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
         rc = zk_ntt_dit(ctx, st->cs->coeffs + (size_t)NC * n, n, d_sig, n, k, R, 0, nullptr, nullptr, 0, nullptr, 0);
         pp.sigmas = d_sig;
         if (rc == ZK_OK) {
-            if (nchunks <= PLK_MAX_CHUNKS) ZK_LAUNCH(ctx, "plonk_perm_rows", plonk_perm_rows_kernel, g1(n), dim3(256), 0, pp);
+            static const int perm_split = getenv("ZK_PLONK_PERM_SPLIT") ? atoi(getenv("ZK_PLONK_PERM_SPLIT")) : 1;
+            if (perm_split && nch <= 8 && nch * nchunks <= 64 && n <= ((size_t)1 << 18))
+                ZK_LAUNCH(ctx, "plonk_perm_rows", plonk_perm_rows_split_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, pp);
+            else if (nchunks <= PLK_MAX_CHUNKS) ZK_LAUNCH(ctx, "plonk_perm_rows", plonk_perm_rows_kernel, g1(n), dim3(256), 0, pp);
             else {
                 u64 *d_den = (u64 *)A_((size_t)nchunks * n * sizeof(u64));
                 if (!d_den) rc = ctx->fail(ZK_ERR_OOM, "prove_plonk: out of device memory");
@@ -536,12 +578,16 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
     }
     ZK_LAUNCH(ctx, "plonk_zeta", plonk_zeta_kernel, dim3(1), dim3(1), 0, d_zeta, k, gl_root(k), ctx->d_err);
     // ---- OpeningSet::new
-    rc = zk_eval_cols_at(ctx, st->cs->coeffs, n, k, NC + R, d_zeta, d_proof + y.o_cs);
-    if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, g.wb->coeffs, n, k, W, d_zeta, d_proof + y.o_w);
-    if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, g.zb->coeffs, n, k, nch, d_zeta, d_proof + y.o_z);
-    if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, g.zb->coeffs, n, k, nch, d_zeta + 2, d_proof + y.o_zn);
-    if (rc == ZK_OK && npp) rc = zk_eval_cols_at(ctx, g.zb->coeffs + (size_t)nch * n, n, k, nch * npp, d_zeta, d_proof + y.o_pp);
-    if (rc == ZK_OK) rc = zk_eval_cols_at(ctx, g.qb->coeffs, n, k, Q, d_zeta, d_proof + y.o_q);
+    {
+        zk_eval_job jobs[6]; u32 nj = 0;
+        jobs[nj++] = {st->cs->coeffs, n, NC + R, d_zeta, d_proof + y.o_cs};
+        jobs[nj++] = {g.wb->coeffs, n, W, d_zeta, d_proof + y.o_w};
+        jobs[nj++] = {g.zb->coeffs, n, nch, d_zeta, d_proof + y.o_z};
+        jobs[nj++] = {g.zb->coeffs, n, nch, d_zeta + 2, d_proof + y.o_zn};
+        if (npp) jobs[nj++] = {g.zb->coeffs + (size_t)nch * n, n, nch * npp, d_zeta, d_proof + y.o_pp};
+        jobs[nj++] = {g.qb->coeffs, n, Q, d_zeta, d_proof + y.o_q};
+        rc = zk_eval_cols_multi(ctx, k, nj, jobs);
+    }
     if (rc) return rc;
     {   // observe_openings(to_fri_openings): zeta batch (constants, sigmas, wires, zs, partial products, quotient), then zs_next
         TOpList a = {}; int q = 0;
