@@ -14,12 +14,25 @@
 // Tables: PSD_WV_INIT[12][64], PSD_WV_CHAIN[22][64] (lane 63 = the round's constant K), PSD_WV_MDS[12][64], PSD_WV_RC[9][64] (the
 // per-lane constants of the full rounds and PR_FIRST) -- 28 KB, staged in LDS by the caller (fill()): every constant the dependent
 // chain needs arrives by a prefetched ds_read, none by a global or scalar load in the middle of the chain.
+//
+// Fast path (round 3): a wave alone on its SIMD pays 5.5-9.5 cycles for EVERY instruction it issues, pads included
+// (tools/ubench_lat.hip), so the two round bodies are hand-scheduled instruction sequences (poseidon_wave_asm.inc, generated, simulated
+// and hazard-checked by tools/gen_wave_asm.py): x^3 and x^4 of an s-box interleaved instruction by instruction, v_readlane two MDS terms
+// ahead of its multiply-adds, the next layer's constants as the starting values of the MDS column sums, the partial rounds' constants
+// K[q] folded into the lanes' starting values (PSD_WV_KSUM), loops unrolled inside the blocks with their table reads as ds_read one round
+// ahead: 117 / 82 instructions per full / partial round against 148 / 120 + the compiler's loop code.
+// The exact twin (every repair in place, taken when the sticky word is up) stays the compiled code below.
 #pragma once
 #include "poseidon.cuh"
+#include "poseidon_wave_asm.inc"
+
+#ifndef PSDW_USE_ASM
+#define PSDW_USE_ASM 1       // 0: the compiled round bodies on the fast path as well (A/B builds)
+#endif
 
 namespace psdw {
 
-constexpr int TAB_WORDS = (12 + 22 + 12 + 9) * 64;      // 28 KB
+constexpr int TAB_WORDS = (12 + 22 + 12 + 9 + 1) * 64;      // 28.5 KB
 
 // all threads of the block copy the two tables into `lds` (TAB_WORDS u64); caller synchronises afterwards
 __device__ __forceinline__ void fill(u64 *lds) {
@@ -27,6 +40,7 @@ __device__ __forceinline__ void fill(u64 *lds) {
     for (int i = threadIdx.x; i < 22 * 64; i += blockDim.x) lds[12 * 64 + i] = PSD_WV_CHAIN[i];
     for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lds[34 * 64 + i] = PSD_WV_MDS[i];
     for (int i = threadIdx.x; i < 9 * 64; i += blockDim.x) lds[46 * 64 + i] = PSD_WV_RC[i];
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) lds[55 * 64 + i] = PSD_WV_KSUM[i];
 }
 
 __device__ __forceinline__ u64 rdlane64(u64 v, int l) {
@@ -74,9 +88,53 @@ template <bool EXACT> struct perm {
         return s;
     }
 
+    // ---- fast path: the generated round bodies (three asm statements per permutation; their table reads are ds_read inside the blocks)
+    __device__ __forceinline__ u64 run_fast(u64 s) {
+        const u32 rc_addr = (u32)(unsigned long)(tab + 46 * 64 + lane);        // this lane's cell of row 0 of the per-lane round constants
+        const u32 ch_addr = (u32)(unsigned long)(tab + 12 * 64 + lane);        // ... of row 0 of the chain coefficients
+        u64 f = 0;
+        // rounds 0..3: the constants of round 0 here, those of rounds 1..3 and PR_FIRST (row 8) by the MDS layers
+        s = psd::wadd_c(s, tab[46 * 64 + lane]);
+        u32 sl = (u32)s, sh = (u32)(s >> 32);
+        asm volatile(PSDW_FULL_ROUNDS_FIRST_ASM
+                     : [sl] "+v"(sl), [sh] "+v"(sh), [fl] "+s"(f)
+                     : [addr] "v"(rc_addr), [m0] "v"(m[0]), [m1] "v"(m[1]), [m2] "v"(m[2]), [m3] "v"(m[3]), [m4] "v"(m[4]), [m5] "v"(m[5]),
+                       [m6] "v"(m[6]), [m7] "v"(m[7]), [m8] "v"(m[8]), [m9] "v"(m[9]), [m10] "v"(m[10]), [m11] "v"(m[11])
+                     : PSDW_ASM_CLOBBERS);
+        // ---- 22 partial rounds: z = state + PR_FIRST is what came out
+        const u64 z = ((u64)sh << 32) | sl;
+        u64 acc;
+        {
+            psd::acc3 a; a.init();
+            a.c0 = tab[55 * 64 + lane];                  // the K[q] of all rounds, folded (PSD_WV_KSUM)
+#pragma unroll
+            for (int i = 0; i < 12; i++) a.mac_s(rdlane64(z, i), tab[64 * i + lane]);
+            acc = pc.reduce(a);
+        }
+        u32 al = (u32)acc, ah = (u32)(acc >> 32);
+        asm volatile(PSDW_PART_ROUNDS_ASM
+                     : [al] "+v"(al), [ah] "+v"(ah), [fl] "+s"(f)
+                     : [addr] "v"(ch_addr)
+                     : PSDW_ASM_CLOBBERS);
+        // final state sits in lanes 32..43
+        al = __shfl(al, (lane + 32) & 63, 64); ah = __shfl(ah, (lane + 32) & 63, 64);
+        // rounds 26..29: rows 4..7, nothing after the last
+        s = psd::wadd_c(((u64)ah << 32) | al, tab[46 * 64 + 4 * 64 + lane]);
+        sl = (u32)s; sh = (u32)(s >> 32);
+        asm volatile(PSDW_FULL_ROUNDS_LAST_ASM
+                     : [sl] "+v"(sl), [sh] "+v"(sh), [fl] "+s"(f)
+                     : [addr] "v"(rc_addr), [m0] "v"(m[0]), [m1] "v"(m[1]), [m2] "v"(m[2]), [m3] "v"(m[3]), [m4] "v"(m[4]), [m5] "v"(m[5]),
+                       [m6] "v"(m[6]), [m7] "v"(m[7]), [m8] "v"(m[8]), [m9] "v"(m[9]), [m10] "v"(m[10]), [m11] "v"(m[11])
+                     : PSDW_ASM_CLOBBERS);
+        pc.fl |= f;
+        s = ((u64)sh << 32) | sl;
+        return lane < 12 ? gl_canon(s) : 0;
+    }
+
     // s: state word `lane` for lane < 12 (any 64-bit representative), ignored elsewhere.  Returns the permuted word, canonical, in
     // lanes 0..11 and 0 in the others.  Must be called by all 64 lanes.
     __device__ __forceinline__ u64 run(u64 s) {
+        if (!EXACT && PSDW_USE_ASM) return run_fast(s);
         s = full_rounds(s, 0);
         // ---- 22 partial rounds
         const u64 z = psd::wadd_c(s, tab[46 * 64 + 8 * 64 + lane]);

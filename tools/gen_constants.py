@@ -170,6 +170,46 @@ def poseidon_wave(state, tabs, wave):
     return s
 
 
+def wave_ksum(wave):
+    """the round constants K[q] folded into the lanes' starting values: sum_q chain[q][lane] * K[q] over the lanes that are read
+    (0..21: x0 before round k, 32..43: the final state); lane k < 22 is read before rounds >= k have added anything (chain[q][k] = 0
+    for q >= k), so the fold is exact for every value that is ever used"""
+    T_init, T_chain = wave
+    ks = [0] * 64
+    for ln in list(range(R_P)) + list(range(32, 44)):
+        assert all(T_chain[q][ln] == 0 for q in range(ln, R_P)) or ln >= 32
+        ks[ln] = sum(T_chain[q][ln] * T_chain[q][63] for q in range(R_P)) % P
+    return ks
+
+
+def poseidon_wave_folded(state, tabs, wave):
+    """poseidon_wave with the K[q] folded into the starting values (the fast path of poseidon_wave.cuh): u_q = x0^7 only"""
+    first, init, k, vhat, wcol, m00 = tabs
+    T_init, T_chain = wave
+    ks = wave_ksum(wave)
+    RC = S.rc()
+    s = [x % P for x in state]
+    r = 0
+    for _ in range(4):
+        s = [(s[i] + RC[12 * r + i]) % P for i in range(12)]
+        s = [pow(x, 7, P) for x in s]
+        s = S._mds(s)
+        r += 1
+    z = [(s[i] + first[i]) % P for i in range(12)]
+    acc = [(sum(T_init[i][ln] * z[i] for i in range(12)) + ks[ln]) % P for ln in range(64)]
+    for q in range(R_P):
+        u = pow(acc[q], 7, P)
+        acc = [(acc[ln] + T_chain[q][ln] * u) % P if ln != 63 else 0 for ln in range(64)]
+    s = [acc[32 + j] for j in range(12)]
+    r += R_P
+    for _ in range(4):
+        s = [(s[i] + RC[12 * r + i]) % P for i in range(12)]
+        s = [pow(x, 7, P) for x in s]
+        s = S._mds(s)
+        r += 1
+    return s
+
+
 def c_array(name, vals, per_line=4, ctype="uint64_t", qual="static const"):
     lines = []
     for i in range(0, len(vals), per_line):
@@ -187,6 +227,7 @@ def main():
     for t in tests:
         assert poseidon_sparse(t, tabs) == S.poseidon(t)
         assert poseidon_wave(t, tabs, wave) == S.poseidon(t)
+        assert poseidon_wave_folded(t, tabs, wave) == S.poseidon(t)
     first, init, k, vhat, wcol, m00 = tabs
     hdr = ("/* GENERATED by tools/gen_constants.py -- do not edit.\n"
            " * Poseidon-Goldilocks round constants = 360 x ChaCha8Rng::seed_from_u64(0).gen_range(0..p)\n"
@@ -227,6 +268,8 @@ def main():
         # per-lane constants of the eight full rounds (rows 0..3: rounds 0..3, rows 4..7: rounds 26..29) and PR_FIRST as row 8
         wrc = [[RC[12 * rnd + l] if l < 12 else 0 for l in range(64)] for rnd in (0, 1, 2, 3, 26, 27, 28, 29)] + [[first[l] if l < 12 else 0 for l in range(64)]]
         f.write(c_array("PSD_WV_RC", [x for row in wrc for x in row], per_line=8, qual="PSD_CONST"))
+        # the partial rounds' constants folded into the lanes' starting values (fast path of poseidon_wave.cuh): see wave_ksum()
+        f.write(c_array("PSD_WV_KSUM", wave_ksum(wave), per_line=8, qual="PSD_CONST"))
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     with open(os.path.join(ROOT, "tests", "golden", "poseidon_rc.json"), "w") as f:
         json.dump({"sha256_le_u64": hashlib.sha256(b"".join(struct.pack("<Q", c) for c in RC)).hexdigest(),
