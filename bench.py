@@ -300,16 +300,16 @@ def main():
         local = local % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
         # finished proofs are host buffers: they are handed to rank 0 over a gloo group.  gloo prints its connection report on
-        # stdout from C++: keep it away from the ONE JSON line this program owes its caller
+        # stdout from C++ (so does the rehearsal's gloo default group): keep it away from the ONE JSON line this program owes its caller
         sys.stdout.flush()
         _fd1 = os.dup(1)
         os.dup2(2, 1)
         try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
             host_pg = sharding.host_group()
         finally:
             os.dup2(_fd1, 1)

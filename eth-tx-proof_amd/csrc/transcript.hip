@@ -162,11 +162,12 @@ int32_t zk_pow_search_dev(zk_ctx *ctx, u32 min_zeros, u64 *d_pow_state) {
     // expected 2^min_zeros candidates; 2^(min_zeros+6) of them fail with probability e^-64.  Later blocks exit early
     // once a smaller witness is recorded.
     u64 total = (u64)1 << (min_zeros + 6 > 40 ? 40 : min_zeros + 6);
-    // Launches grow: the first covers 4 x the expected search (misses with probability e^-4), the next 16 x, the last the rest.  A
-    // later launch costs its blocks one load each once a witness is known -- three launches instead of 32 equal ones, which were 2 ms
-    // of launch latency per seven-table unit.
+    // Launches grow: the first covers the expected search (2^min_zeros candidates: one wave per SIMD at 16 bits, i.e. ONE permutation's
+    // latency; misses with probability 1/e), the next 4 x, the last the rest.  A later launch costs its blocks one load each once a
+    // witness is known.  (Round 2 started with 4 x the expected search: every proof paid 2^18 permutations, 160 us, where 2^16 + 0.37 x
+    // 2^18 are enough on average; before that, 32 equal launches were 2 ms of launch latency per seven-table unit.)
     u64 base = 0;
-    const u64 first = (u64)1 << (min_zeros + 2), second = (u64)1 << (min_zeros + 4);
+    const u64 first = (u64)1 << min_zeros, second = (u64)1 << (min_zeros + 2);
     const u64 cuts[3] = {first < total ? first : total, second < total ? second : total, total};
     for (int k = 0; k < 3; k++) {
         if (cuts[k] <= base) continue;

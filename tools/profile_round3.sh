@@ -12,6 +12,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- p
 echo "rocprof stats done"
 python3 tools/plonk_bench.py 13 5 > $OUT/plonk_bench_2p13.txt 2>&1 || { echo "plonk bench failed"; tail -5 $OUT/plonk_bench_2p13.txt; exit 1; }
 NO_ORACLE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_plonk -o plonk -- python3 tools/plonk_bench.py 13 20 > $OUT/plonk_under_rocprof.txt 2>&1 || { echo "rocprof plonk failed"; exit 1; }
+python3 tools/plonk_bench.py 12 5 > $OUT/plonk_bench_2p12.txt 2>&1 || { echo "plonk bench 2^12 failed"; exit 1; }
+python3 tools/cfg4_bench.py > $OUT/cfg4_bench.txt 2>&1 || { echo "cfg4 bench failed"; tail -5 $OUT/cfg4_bench.txt; exit 1; }
+[ -x tools/bin/ubench_lat ] && tools/bin/ubench_lat > $OUT/ubench_lat_gfx950.txt 2>&1
 echo "plonk done"
 python3 bench.py --workload prove_root --steps 4 > $OUT/bench_prove_root.json 2> $OUT/bench_prove_root.err || { echo "prove_root bench failed"; tail -5 $OUT/bench_prove_root.err; exit 1; }
 echo "prove_root done"
