@@ -50,6 +50,7 @@ def parse_args():
                     help="independent unit proofs in flight per GPU, one stream each (default 4; 2 at 2^22 rows and above)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host-resident traces) measurement")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the newest committed PMC pass instead of a live rocprofv3 --pmc child run")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled repeat (no kernel table / roofline)")
     ap.add_argument("--chain-streams", type=int, default=3, help="--workload prove_root: shrink chains of ONE transaction proved side by side by its worker")
     ap.add_argument("--workload", choices=["stark_unit", "prove_root"], default="stark_unit",
@@ -254,6 +255,41 @@ def golden_digest(log_n, n_cols, n_helpers, seed):
         if (e["log_n"], e["n_cols"], e["n_helpers"], e["seed"]) == (log_n, n_cols, n_helpers, seed):
             return e["sha256"]
     return None
+
+
+def live_pmc_bytes(log_n, n_cols, timeout_s=150):
+    """HBM bytes of ONE leaf-hash launch from the PMC counters, collected NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: each in
+    a run of its own with --kernel-trace only, as the pool requires) over a child process that commits one n_cols-column 2^log_n-row batch
+    (tools/commit_bench.py: the very leaf-hash launch of the bench's unit).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
+    gfx950 (128-B requests tallied at 64 B); both counters are in KB.  Returns (bytes, detail) or raises: the caller falls back to the
+    newest committed pass."""
+    import csv, shutil, tempfile
+    if not shutil.which("rocprofv3"):
+        raise RuntimeError("rocprofv3 not on PATH")
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("this process already runs under a profiler")
+    kern = "hash_leaves_colmajor_mfma_kernel"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="zk_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", d, "-o", "c", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "commit_bench.py"), str(log_n), str(n_cols), "1"],
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "c_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError("rocprofv3 --pmc %s: rc %d%s" % (counter, r.returncode, "" if files else ", no counter file"))
+            tot, cnt = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if row["Kernel_Name"].startswith(kern) and row["Counter_Name"] == counter:
+                    tot += float(row["Counter_Value"]); cnt += 1
+            if not cnt:
+                raise RuntimeError("rocprofv3 --pmc %s: no %s dispatch in the counter file" % (counter, kern))
+            vals[counter] = tot / cnt
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"]}
 
 
 def int_alu_peak():
@@ -517,6 +553,15 @@ def main():
                 pmf = newest_profile("r*_pmc_leaf_hash.json")
                 pm = json.load(open(pmf))["leaf_hash_93cols"]
                 traffic = per_launch * pm["pmc_bytes"] / pm["algorithmic_bytes"]
+                traffic_src = {"source": "committed " + os.path.basename(pmf), "scaled_from_93_columns": dcols != 93}
+                if not args.no_live_pmc and world == 1:
+                    # ... measured in THIS run when the profiler is there: a child process under rocprofv3 --pmc (two passes, ~10 s each)
+                    try:
+                        traffic, det = live_pmc_bytes(args.log_n, dcols)
+                        traffic_src = dict(det, source="live: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- tools/commit_bench.py %d %d 1, "
+                                                       "2 x FETCH_SIZE + WRITE_SIZE (KB), mean over the dispatches of the kernel" % (args.log_n, dcols))
+                    except Exception as e:       # no profiler, refused, timed out: the committed pass stands, and the line says so
+                        traffic_src["live_attempt_failed"] = str(e)[:200]
                 perms_per_launch = (2 * n) * (-(-dcols // 8))
                 vw = pm["valu_instr_per_wave_permutation"]
                 peak_wi, ubf = int_alu_peak()
@@ -532,7 +577,7 @@ def main():
                                "instructions per 64-permutation wave (SQ_INSTS_VALU)"}
             line["roofline"] = {
                 "bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "alu": alu,
+                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src if dcols is not None else None, "alu": alu,
                 "avg_launch_ms": dms / dlaunch, "avg_launch_ms_alone": solo_avg_ms, "launches": dlaunch,
                 "algorithmic_bytes_per_launch": per_launch, "share_of_kernel_time": dms / tot_ms,
                 "note": "Poseidon hashing is integer-ALU-bound; the HBM fraction is reported as the contract asks, `alu` and "

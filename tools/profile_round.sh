@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-live-pmc > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
     tag=$(echo $C | tr ' ' '+')
     rocprofv3 --kernel-trace --output-format csv --pmc $C -d $OUT/pmc_$tag -o c -- python3 tools/commit_bench.py 20 93 1 > $OUT/pmc_$tag.log 2>&1 || echo "pmc pass $tag failed" >> $OUT/errors.txt

@@ -8,7 +8,7 @@ rm -rf $OUT && mkdir -p $OUT
 cd $R
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || { echo "default bench failed"; tail -5 $OUT/bench_default.err; exit 1; }
 echo "default bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-pcie > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || { echo "rocprof bench failed"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-pcie --no-live-pmc > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || { echo "rocprof bench failed"; exit 1; }
 echo "rocprof stats done"
 python3 tools/plonk_bench.py 13 5 > $OUT/plonk_bench_2p13.txt 2>&1 || { echo "plonk bench failed"; tail -5 $OUT/plonk_bench_2p13.txt; exit 1; }
 NO_ORACLE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_plonk -o plonk -- python3 tools/plonk_bench.py 13 20 > $OUT/plonk_under_rocprof.txt 2>&1 || { echo "rocprof plonk failed"; exit 1; }
