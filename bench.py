@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (host-resident traces) measurement")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the newest committed PMC pass instead of a live rocprofv3 --pmc child run")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled repeat (no kernel table / roofline)")
+    ap.add_argument("--chain-overlap", type=int, default=-1, help="--workload prove_root: 1 = a table's shrink chain starts under the STARK proofs of the later tables, 0 = after all of "
+                    "them, -1 (default) = the prover state's own rule: overlap while at most two transactions are in flight")
     ap.add_argument("--chain-streams", type=int, default=3, help="--workload prove_root: shrink chains of ONE transaction proved side by side by its worker")
     ap.add_argument("--workload", choices=["stark_unit", "prove_root"], default="stark_unit",
                     help="stark_unit (default, BASELINE's metric): one unit STARK proof per step and worker.  prove_root: one TRANSACTION end to end "
@@ -72,7 +74,7 @@ def bench_prove_root(args):
         sys.exit("bench.py --workload prove_root: one GPU only (transactions shard over ranks exactly like the units of the default workload)")
     inflight = args.inflight or 8
     rec = plonk.SyntheticRecursion()
-    st = ops.set_prover_state_from_config(0, recursion=rec, chain_streams=args.chain_streams)
+    st = ops.set_prover_state_from_config(0, recursion=rec, chain_streams=args.chain_streams, chain_overlap={0: False, 1: True}.get(args.chain_overlap, "auto"))
 
     def unit(ctx):
         tabs = []
@@ -136,7 +138,7 @@ def bench_prove_root(args):
         "config": {"workload": "BASELINE configs[3] end to end: seven tables (log sizes %s, widths %s) on one challenger, shrink chains %s (degree bits), "
                                "root 2^%d; recursion circuits: stand-ins of the recursion shape (plonk.SyntheticRecursion), standard_recursion_config"
                                % (list(air.ZKEVM_CFG4_LOG_SIZES), list(air.ZKEVM_TABLE_WIDTHS), chains, rec._bits(rec.ROOT_BITS)),
-                   "tx_per_step_per_gpu": inflight, "shrink_chains_side_by_side_per_tx": args.chain_streams, "parallelism": "independent transactions, 1 GPU"},
+                   "tx_per_step_per_gpu": inflight, "shrink_chains_side_by_side_per_tx": args.chain_streams, "shrink_chains_start_under_the_later_tables_stark_proofs": {0: "never", 1: "always"}.get(args.chain_overlap, "auto: with at most 2 transactions in flight (so: for one_tx_alone_ms, not in the timed region unless --inflight <= 2)"), "parallelism": "independent transactions, 1 GPU"},
         "one_tx_alone_ms": {"total": sum(split.values()) * 1e3, "stark_proofs": split["stark_s"] * 1e3,
                             "shrink_chains_%d_plonk_proofs" % sum(len(c) for c in chains): split["shrink_s"] * 1e3, "root_proof": split["root_s"] * 1e3},
         "kernels_one_tx_alone": kern, "roofline": None, "cpu_baseline": None,

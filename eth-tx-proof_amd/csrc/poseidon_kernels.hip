@@ -370,6 +370,39 @@ __global__ __launch_bounds__(256) void merkle_level_wave_kernel(const u64 *__res
     if (lane < 4) parent[4 * j + lane] = s;
 }
 
+// Several of the smallest levels in ONE launch: a workgroup of 2^(LV-1) waves owns 2^LV adjacent nodes of the level below and walks up to
+// their one ancestor -- wave w hashes parent w, the digests meet in LDS, half the waves go on.  Every level is also written to the
+// levels array (the tree keeps all of them for the openings).  A level of the one-parent-per-wave kernel is one permutation (7.5 us)
+// plus a launch and the 28 KB table image (as much again): the eight levels below 2 048 parents of a tree are two launches here.
+template <int LV>
+__global__ __launch_bounds__(64 << (LV - 1)) void merkle_tail_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parents, u64 force_redo) {
+    constexpr int NW = 1 << (LV - 1);
+    __shared__ u64 wtab[psdw::TAB_WORDS];
+    __shared__ u64 dig[2][NW * 4];
+    psdw::fill(wtab); __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;            // w: wave-uniform
+    size_t cnt = n_parents;                                              // a multiple of NW (launcher)
+    u64 *out = parent;
+    {
+        const size_t j = (size_t)blockIdx.x * NW + w;
+        u64 s = lane < 8 ? child[8 * j + lane] : 0;
+        s = psdw::permute(s, lane, wtab, force_redo);
+        if (lane < 4) { out[4 * j + lane] = s; dig[0][4 * w + lane] = s; }
+    }
+#pragma unroll
+    for (int lv = 1; lv < LV; lv++) {
+        __syncthreads();
+        out += 4 * cnt; cnt >>= 1;
+        const int active = NW >> lv;
+        if (w < active) {
+            u64 s = lane < 8 ? dig[(lv - 1) & 1][8 * w + lane] : 0;
+            s = psdw::permute(s, lane, wtab, force_redo);
+            const size_t j = (size_t)blockIdx.x * active + w;
+            if (lane < 4) { out[4 * j + lane] = s; dig[lv & 1][4 * w + lane] = s; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void permute_batch_kernel(u64 *states, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -485,9 +518,30 @@ int32_t zk_merkle_levels(zk_ctx *ctx, u64 *levels, size_t n_leaves, uint32_t cap
             else
                 ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_mfma_kernel, dim3((unsigned)(cnt / 2 / 256)), dim3(256), 0, T, (const u64 *)cur, nxt, cnt / 2,
                           ctx->force_redo);
-        } else if (cnt / 2 <= 2048 && !(ctx->poseidon_mfma & 8))
+        } else if (cnt / 2 <= 2048 && !(ctx->poseidon_mfma & 8)) {
+            // levels left down to the cap; up to five of them in one launch while the parents divide into whole workgroups
+            // ZK_MERKLE_TAIL = most levels per launch (2..5; 0 = one launch per level).  OFF by default: measured, a transaction alone gains
+            // 0.05 ms per Plonk proof, and with eight transactions in flight the mostly idle 16-wave workgroups block whole compute units:
+            // 23.0 -> 17.5 tx/s at 5 levels
+            static const int tail = getenv("ZK_MERKLE_TAIL") ? atoi(getenv("ZK_MERKLE_TAIL")) : 0;
+            int left = 0;
+            for (size_t c = cnt; c > ((size_t)1 << cap_height); c >>= 1) left++;
+            int lv = left < tail ? left : tail;
+            if (lv > 5) lv = 5;
+            while (lv > 1 && (cnt / 2) % ((size_t)1 << (lv - 1))) lv--;
+            if (tail >= 2 && lv >= 2) {
+                const unsigned nw = 1u << (lv - 1), grid = (unsigned)((cnt / 2) / nw);
+                switch (lv) {
+                case 5: ZK_LAUNCH(ctx, "poseidon_merkle_level_wave", merkle_tail_kernel<5>, dim3(grid), dim3(64 * nw), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo); break;
+                case 4: ZK_LAUNCH(ctx, "poseidon_merkle_level_wave", merkle_tail_kernel<4>, dim3(grid), dim3(64 * nw), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo); break;
+                case 3: ZK_LAUNCH(ctx, "poseidon_merkle_level_wave", merkle_tail_kernel<3>, dim3(grid), dim3(64 * nw), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo); break;
+                default: ZK_LAUNCH(ctx, "poseidon_merkle_level_wave", merkle_tail_kernel<2>, dim3(grid), dim3(64 * nw), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo); break;
+                }
+                for (int q = 0; q < lv; q++) { cur += 4 * cnt; cnt >>= 1; }
+                continue;
+            }
             ZK_LAUNCH(ctx, "poseidon_merkle_level_wave", merkle_level_wave_kernel, dim3((unsigned)((cnt / 2 + 3) / 4)), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo);
-        else if (cnt / 2 <= 16384)
+        } else if (cnt / 2 <= 16384)
             ZK_LAUNCH(ctx, "poseidon_merkle_level_coop", merkle_level_coop_kernel, grid1(cnt / 2 * 16), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2);
         else
             ZK_LAUNCH(ctx, "poseidon_merkle_level", merkle_level_kernel, grid1(cnt / 2), dim3(256), 0, (const u64 *)cur, nxt, cnt / 2, ctx->force_redo);

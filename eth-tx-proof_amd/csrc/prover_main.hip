@@ -92,7 +92,7 @@ extern "C" size_t zk_proof_size_words(const zk_stark_config *cfg, uint32_t n_tab
 static inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
-                                 uint64_t *proof_out, size_t cap_words, size_t *len_words);
+                                 uint64_t *proof_out, size_t cap_words, size_t *len_words, zk_table_ready_fn on_table, void *user);
 
 // Round 1 serialised the first proof of a process behind a mutex ("cold start") after sporadic GPU memory faults in bench.py.  The
 // fault hunt of round 2 (tools/stress_faults.py: 8 streams x 100 full-size proofs x {build-time, hiprtc, interpreter} kernels x
@@ -101,21 +101,25 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
 // the serialisation is off by default; ZK_COLD_MUTEX=1 brings it back.  That hunt prepared the kernels on one thread first: the one
 // scenario it did not cover -- several threads compiling and loading code objects at their FIRST proofs (ZK_QUOTIENT_JIT=1 / 2: hiprtc at
 // first use) -- keeps the mutex unless ZK_COLD_MUTEX=0 says otherwise.
-extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
-                                   uint64_t *proof_out, size_t cap_words, size_t *len_words) {
+extern "C" int32_t zk_prove_tables_notify(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
+                                          uint64_t *proof_out, size_t cap_words, size_t *len_words, zk_table_ready_fn on_table, void *user) {
     static std::atomic<bool> warm{false};
     static std::mutex cold_mu;
     static const bool cold_env = getenv("ZK_COLD_MUTEX") != nullptr, cold_on = cold_env && atoi(getenv("ZK_COLD_MUTEX"));
     const bool cold = cold_env ? cold_on : (ctx && ctx->quotient_jit_mode >= 1);
-    if (!cold || warm.load(std::memory_order_acquire)) return prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
+    if (!cold || warm.load(std::memory_order_acquire)) return prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words, on_table, user);
     std::lock_guard<std::mutex> lk(cold_mu);
-    int32_t rc = prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words);
+    int32_t rc = prove_tables_impl(ctx, cfgp, nt, tables, proof_out, cap_words, len_words, on_table, user);
     if (rc == ZK_OK) warm.store(true, std::memory_order_release);
     return rc;
 }
+extern "C" int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
+                                   uint64_t *proof_out, size_t cap_words, size_t *len_words) {
+    return zk_prove_tables_notify(ctx, cfgp, nt, tables, proof_out, cap_words, len_words, nullptr, nullptr);
+}
 
 static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint32_t nt, const zk_table *tables,
-                                 uint64_t *proof_out, size_t cap_words, size_t *len_words) {
+                                 uint64_t *proof_out, size_t cap_words, size_t *len_words, zk_table_ready_fn on_table, void *user) {
     if (!ctx || !cfgp || !tables || nt == 0 || !proof_out) return ZK_ERR_INVALID_ARG;
     const zk_stark_config &cfg = *cfgp;
     if (cfg.num_challenges == 0 || cfg.num_challenges > 4 || cfg.rate_bits != 1 || cfg.cap_height > 8 || cfg.fri_arity_bits < 2 || cfg.fri_arity_bits > 6)
@@ -137,6 +141,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
     if (cap_words < total) return ctx->fail(ZK_ERR_BUFFER_TOO_SMALL, "prove: proof buffer too small");
 
     int32_t rc = ZK_OK;
+    std::vector<hipEvent_t> table_done;
     // Everything this proof allocates is handed back on EVERY exit path, and only after the stream has drained: an early return
     // must not let the next proof of this context reuse pinned staging or scratch that an enqueued copy or kernel still reads.
     struct Guard {
@@ -311,6 +316,20 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
             zk_transcript_run(ctx, ch, a);
         }
         { ProfScope ph(ctx, "phase: compute openings proof"); rc = zk_fri_prove_dev(ctx, cfg, ch, trace_b[t], aux_b[t], quot_b[t], d_zeta, d_proof, y.fri); }
+        // this table's StarkProof is final: with a listener, its words go to the host now (the later tables are proved meanwhile)
+        if (on_table && rc == ZK_OK) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess ||
+                hipMemcpyAsync(h_out + lay[t].base, d_proof + lay[t].base, (lay[t].end - lay[t].base) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipEventRecord(e, ctx->stream) != hipSuccess) { if (e) hipEventDestroy(e); rc = ctx->fail(ZK_ERR_HIP, "prove: per-table hand-off"); break; }
+            table_done.push_back(e);
+        }
+    }
+    // everything is enqueued (the host runs tens of milliseconds ahead of the GPU here): hand the tables over as they finish
+    for (u32 t = 0; t < (u32)table_done.size(); t++) {
+        if (rc == ZK_OK && hipEventSynchronize(table_done[t]) != hipSuccess) rc = ctx->fail(ZK_ERR_HIP, "prove: per-table hand-off");
+        if (rc == ZK_OK) on_table(user, t, h_out + lay[t].base, lay[t].end - lay[t].base);
+        hipEventDestroy(table_done[t]);
     }
 
     // ---- the only host synchronisation of the proof: fetch the proof bytes and the device error word

@@ -352,15 +352,34 @@ def proof_size_words(cfg, items):
     return f(C.byref(cfg), C.c_uint32(len(items)), arr)
 
 
-def prove_tables(ctx, cfg, items, out=None):
-    """zk_prove_tables: the STARK proofs of all tables of one unit of work; returns the proof words (numpy uint64)."""
+_TABLE_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.c_size_t)
+
+
+def prove_tables(ctx, cfg, items, out=None, on_table=None):
+    """zk_prove_tables: the STARK proofs of all tables of one unit of work; returns the proof words (numpy uint64).
+    on_table(t, words): zk_prove_tables_notify -- called (on this thread, tables in order) as soon as table t's StarkProof words are on
+    the host, while the later tables are still being proved; `words` is a copy.  An exception it raises is re-raised after the call."""
     arr, keep = _tables(items)
     n = proof_size_words(cfg, items)
     if out is None:
         out = np.empty(n, dtype=np.uint64)
     ln = C.c_size_t(0)
-    rc = lib().zk_prove_tables(ctx.h, C.byref(cfg), C.c_uint32(len(items)), arr, _p(out), C.c_size_t(out.size), C.byref(ln))
-    ctx._chk(rc, "zk_prove_tables")
+    if on_table is None:
+        rc = lib().zk_prove_tables(ctx.h, C.byref(cfg), C.c_uint32(len(items)), arr, _p(out), C.c_size_t(out.size), C.byref(ln))
+        ctx._chk(rc, "zk_prove_tables")
+        return out[:ln.value]
+    raised = []
+
+    def cb(_user, t, words, n_words):
+        try:
+            on_table(int(t), np.ctypeslib.as_array(words, shape=(int(n_words),)).copy())
+        except BaseException as e:       # a ctypes callback cannot propagate: kept for the caller
+            raised.append(e)
+    fn = _TABLE_READY_FN(cb)
+    rc = lib().zk_prove_tables_notify(ctx.h, C.byref(cfg), C.c_uint32(len(items)), arr, _p(out), C.c_size_t(out.size), C.byref(ln), fn, None)
+    ctx._chk(rc, "zk_prove_tables_notify")
+    if raised:
+        raise raised[0]
     return out[:ln.value]
 
 

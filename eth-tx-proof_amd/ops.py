@@ -90,13 +90,21 @@ class RecursionCircuits:
 class ProverState:
     """Per-process immutable prover state: StarkConfig + one zk_ctx per worker thread (+ the recursion circuits, if supplied)."""
 
-    def __init__(self, device=0, config=None, recursion: Optional[RecursionCircuits] = None, stark_only=False, chain_streams=3):
+    def __init__(self, device=0, config=None, recursion: Optional[RecursionCircuits] = None, stark_only=False, chain_streams=3, chain_overlap="auto"):
         """stark_only: TxProof.execute stops after the STARK proofs (BASELINE's headline unit) instead of failing for want of
         recursion circuits; never set together with `recursion`.  chain_streams: how many of a transaction's (independent) shrink
         chains one worker proves side by side, each on a context / stream of its own (1: one after another, as upstream's loop; 3 measured
         best on one MI355X: 147 -> 110 ms for one transaction alone, 16.1 -> 20.9 tx/s with eight in flight)."""
         self.device = device
         self.chain_streams = max(1, int(chain_streams))
+        # chain_overlap: a table's shrink chain starts when that table's StarkProof is final, under the STARK proofs of the later tables
+        # (zk_prove_tables_notify); False: prove(), then the chains (chain_streams of them side by side), upstream's order in time.
+        # Measured on one MI355X: alone a transaction takes 77 ms instead of 89, but with 4 / 8 transactions in flight the GPU has no idle
+        # issue slots left to hide the chains in and the extra streams cost 10 % (19.4 against 21.7 / 22.6 tx/s).  "auto" (default): overlap
+        # while at most `overlap_max_inflight` prove_root calls of this process are running.
+        self.chain_overlap = chain_overlap if chain_overlap in (True, False) else "auto"
+        self.overlap_max_inflight = 2
+        self._active, self._active_lock = 0, threading.Lock()
         self.config = config or standard_fast_config()
         self.recursion = recursion
         self.stark_only = bool(stark_only) and recursion is None
@@ -153,13 +161,13 @@ P_STATE: Optional[ProverState] = None
 _lock = threading.Lock()
 
 
-def set_prover_state_from_config(device=0, config=None, recursion=None, stark_only=False, chain_streams=3):
+def set_prover_state_from_config(device=0, config=None, recursion=None, stark_only=False, chain_streams=3, chain_overlap="auto"):
     """Initialises the global prover state once; a second call leaves the first state in place and returns it
     (the reference only warns on double initialisation, worker/src/main.rs:25-27)."""
     global P_STATE
     with _lock:
         if P_STATE is None:
-            P_STATE = ProverState(device, config, recursion, stark_only, chain_streams)
+            P_STATE = ProverState(device, config, recursion, stark_only, chain_streams, chain_overlap)
         return P_STATE
 
 
@@ -197,16 +205,23 @@ def prove_root(input: "GenerationInputs", timing: Optional[dict] = None):
     if rc is None:
         raise FatalError("generate_txn_proof: no recursion circuits in the prover state (SURVEY.md 8f-2, A10): pass ProverState(recursion=...)")
     ctx = st.ctx()
+    with st._active_lock:
+        st._active += 1
+        overlap = st.chain_overlap is True or (st.chain_overlap == "auto" and st._active <= st.overlap_max_inflight)
+    try:
+        return _prove_root(st, rc, ctx, input, timing, overlap)
+    finally:
+        with st._active_lock:
+            st._active -= 1
+
+
+def _prove_root(st, rc, ctx, input, timing, overlap):
     t0 = time.time()
-    all_proof = prove(input)
-    t1 = time.time()
-    jobs = []
-    for ti, (t, words) in enumerate(zip(input.tables, split_all_proof(st.config, input.tables, all_proof))):
-        try:
-            jobs.append((ti, t, words, rc.shrink_chain(ti, t.air, t.log_n)))
-        except KeyError as e:
-            raise FatalError(str(e.args[0])) from e
-    shrunk = [None] * len(jobs)
+    try:            # by_table[t].by_stark_size[degree_bits]: a size without circuits is an error whatever else happens
+        chains = [rc.shrink_chain(ti, t.air, t.log_n) for ti, t in enumerate(input.tables)]
+    except KeyError as e:
+        raise FatalError(str(e.args[0])) from e
+    shrunk = [None] * len(input.tables)
 
     def shrink(c, ti, t, words, chain):
         """by_table[ti].by_stark_size[log_n].shrink(stark_proof): initial wrapper, then every shrinking wrapper, on context c"""
@@ -216,30 +231,71 @@ def prove_root(input: "GenerationInputs", timing: Optional[dict] = None):
             state, wires, pubs = rc.shrinking_wrapper(c, ti, t.air, t.log_n, step, proof)
             proof = zl.prove_plonk(state, wires, pubs, ctx=c)
         shrunk[ti] = proof
-    k = min(st.chain_streams, len(jobs))
-    if k <= 1:
-        for j in jobs:
-            shrink(ctx, *j)
+    k = min(st.chain_streams, len(input.tables))
+    if k <= 1 or not overlap:
+        # upstream's order: prove(), then the chains -- one after another, or k of them side by side (independent until the root
+        # proof), the longest first, each on a stream of its own
+        all_proof = prove(input)
+        t1 = time.time()
+        jobs = [(ti, t, words, chains[ti]) for ti, (t, words) in enumerate(zip(input.tables, split_all_proof(st.config, input.tables, all_proof)))]
+        if k <= 1:
+            for j in jobs:
+                shrink(ctx, *j)
+        else:
+            order = sorted(jobs, key=lambda j: -sum(1 << b for _, _, b in j[3]))
+            lock, errs = threading.Lock(), []
+
+            def run_sorted(c):
+                while True:
+                    with lock:
+                        if not order or errs:
+                            return
+                        j = order.pop(0)
+                    try:
+                        shrink(c, *j)
+                    except Exception as e:
+                        errs.append(e)
+            th = [threading.Thread(target=run_sorted, args=(c,)) for c in [ctx] + st.side_ctxs(k - 1)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            if errs:
+                raise errs[0]
     else:
-        # the chains are independent until the root proof: k of them side by side, the longest first, each on a stream of its own
-        order = sorted(jobs, key=lambda j: -sum(1 << b for _, _, b in j[3]))
-        lock, errs = threading.Lock(), []
+        # A table's chain needs that table's StarkProof and nothing else, and the tables are proved one after another on one challenger:
+        # k workers (a stream of their own each) start a chain the moment its table's proof is on the host (zk_prove_tables_notify),
+        # under the STARK proofs of the tables that follow.  Same values as upstream's sequence, in another order in time.
+        import queue
+        q, errs = queue.Queue(), []
 
         def run(c):
             while True:
-                with lock:
-                    if not order or errs:
-                        return
-                    j = order.pop(0)
+                j = q.get()
+                if j is None:
+                    return
+                if errs:
+                    continue
                 try:
                     shrink(c, *j)
                 except Exception as e:
                     errs.append(e)
-        th = [threading.Thread(target=run, args=(c,)) for c in [ctx] + st.side_ctxs(k - 1)]
+        th = [threading.Thread(target=run, args=(c,)) for c in st.side_ctxs(k)]
         for x in th:
             x.start()
-        for x in th:
-            x.join()
+        try:
+            items = [(t.air, t.log_n, t.trace, t.public_inputs) for t in input.tables]
+            all_proof = zl.prove_tables(ctx, st.config, items,
+                                        on_table=lambda ti, words: q.put((ti, input.tables[ti], words, chains[ti])))
+            t1 = time.time()
+        except BaseException:
+            errs.append(None)            # what the workers derived from a refused proof is dropped
+            raise
+        finally:
+            for _ in th:
+                q.put(None)
+            for x in th:
+                x.join()
         if errs:
             raise errs[0]
     t2 = time.time()

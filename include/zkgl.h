@@ -283,6 +283,16 @@ size_t zk_proof_size_words(const zk_stark_config *cfg, uint32_t n_tables, const 
  * assert!(degree_bits >= arity_bits)) is refused the same way; zk_proof_size_words returns 0 for every refused combination. */
 int32_t zk_prove_tables(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables,
                         uint64_t *proof_out, size_t proof_cap_words, size_t *proof_len_words);
+/* The same proof, with a notification per table: tables are proved one after another on one challenger, and table t's StarkProof is
+ * final long before the last table's -- `on_table(user, t, words, n_words)` is called (on the calling thread, tables in order) as soon as
+ * table t's words have reached the host, while the later tables are still being proved on the GPU.  prove_root uses it to start a
+ * table's shrink chain (by_table[t].by_stark_size[..].shrink, independent of the other tables) under the STARK proofs of the tables
+ * that follow; upstream's loop (prove(), then the chains) computes the same values in sequence.  `words` points into the context's
+ * pinned download buffer: copy before returning.  The device-side error word is checked after the LAST table as always: a callback may
+ * see the words of a proof that the call then refuses (a consumer must drop what it derived when the call fails). */
+typedef void (*zk_table_ready_fn)(void *user, uint32_t table, const uint64_t *words, size_t n_words);
+int32_t zk_prove_tables_notify(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables,
+                               uint64_t *proof_out, size_t proof_cap_words, size_t *proof_len_words, zk_table_ready_fn on_table, void *user);
 /* Prover state: what the reference builds once at start-up (common/src/prover_state/mod.rs:59-95, used through
  * ops::p_state, ops/src/lib.rs:16-18).  Here: the constraint programs of the given tables compiled to gfx950 code (hiprtc) and
  * cached for the process (and in the prover-state directory, zk_prover_state_cache_dir); without this call proofs evaluate

@@ -194,3 +194,13 @@ def test_chunked_constraint_kernel_source_compiles_for_gfx950(zk, tmp_path):
     buf = C.create_string_buffer(ln.value + 1)
     assert L.zk_quotient_kernel_source(small.ref, C.c_uint32(2), C.c_uint32(1), buf, C.c_size_t(ln.value + 1), C.byref(ln), C.byref(kh)) == 0
     assert "__noinline__" not in buf.value.decode()
+
+
+def test_wave_permutation_round_bodies_are_what_the_generator_emits_and_pass_its_checks():
+    """poseidon_wave_asm.inc (the hand-scheduled round bodies of the wave-wide permutation) is generated: the committed text must be the
+    generator's output, and the generator's own checks -- a 64-lane simulation of every emitted instruction against the field arithmetic
+    and the two-wait-state rule for vector-written SGPRs -- must pass.  (The GPU suite then runs the kernels against the oracle.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wave_asm.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -213,3 +213,48 @@ def test_gate_program_compiled_at_setup_equals_interpreter_and_oracle(ctx, zk, o
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_PLONK_JIT="0"), timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == hashlib.sha256(ref.tobytes()).hexdigest()
+
+
+def test_round3_launch_shapes_are_switches_not_results(ctx, zk):
+    """The round-3 launch shapes -- an LDE's cosets in one launch per pass, 2^11 / 2^12 transforms as one whole-row pass, permutation rows
+    spread over the workgroup -- must not show in any result: a child process with the switches OFF (they are read once per process)
+    commits the same columns and proves the same circuit; caps and proof words must equal this process's."""
+    import hashlib, json, os, subprocess, sys
+    from eth_tx_proof_amd import plonk
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, %r)
+import eth_tx_proof_amd as E
+from eth_tx_proof_amd import lib as zl, plonk
+ctx = zl.Context(0)
+out = {}
+rng = np.random.default_rng(5)
+for k, c in ((5, 3), (11, 9), (12, 20), (13, 7)):
+    vals = rng.integers(0, 0xFFFFFFFF00000001, size=(c, 1 << k), dtype=np.uint64)
+    b = ctx.batch_from_values(vals, rate_bits=3, cap_height=4)
+    out["cap_%%d" %% k] = hashlib.sha256(np.ascontiguousarray(b.cap).tobytes()).hexdigest()
+    b.free()
+cfg = E.standard_recursion_config()
+for k in (6, 12):
+    circ, wires = plonk.synthetic_circuit(degree_bits=k, seed=k)
+    st = zl.PlonkState(ctx, cfg, circ)
+    out["plonk_%%d" %% k] = hashlib.sha256(zl.prove_plonk(st, wires, np.arange(3, dtype=np.uint64)).tobytes()).hexdigest()
+    st.free()
+print("RESULT " + json.dumps(out))
+""" % root
+
+    def run(env_extra):
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    on = run({})
+    off = run({"ZK_NTT_COSET_MERGE": "0", "ZK_NTT_ROW_W": "10", "ZK_PLONK_PERM_SPLIT": "0"})
+    assert on == off
+    # and this process (defaults) agrees with both on one of them
+    rng = np.random.default_rng(5)
+    vals = rng.integers(0, 0xFFFFFFFF00000001, size=(3, 1 << 5), dtype=np.uint64)
+    b = ctx.batch_from_values(vals, rate_bits=3, cap_height=4)
+    assert hashlib.sha256(np.ascontiguousarray(b.cap).tobytes()).hexdigest() == on["cap_5"]
+    b.free()

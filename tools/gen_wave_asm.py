@@ -11,7 +11,7 @@ only six pads per round remain.  The sequences use fixed scratch registers (v96.
 Checked HERE, before anything is compiled: (1) a lane-accurate simulation of every emitted instruction against the field arithmetic
 (full round = MDS(sbox(s)) + next constants, partial round = acc + c * x0^7), (2) the hazard rule the library's kernels obey on gfx950
 (a vector-written SGPR / VCC is read by a vector instruction no sooner than two issue slots later).
-usage: python tools/gen_wave_asm.py            (writes the .inc; exits non-zero if a check fails)"""
+usage: python tools/gen_wave_asm.py [--check]   (writes the .inc, or with --check compares it; exits non-zero if a check fails)"""
 import os
 import random
 import sys
@@ -457,6 +457,11 @@ def main():
         lines += ['    "%s\\n\\t" \\' % x for x in t]
         lines.append('    ""')
     path = os.path.join(ROOT, "eth-tx-proof_amd", "csrc", "poseidon_wave_asm.inc")
+    if "--check" in sys.argv:        # the committed file must be what this generator emits (tests/test_abi_cpu.py)
+        if open(path).read() != "\n".join(lines) + "\n":
+            raise SystemExit("%s is not what tools/gen_wave_asm.py emits: run the generator" % path)
+        print("ok: %s is current; simulation and hazard check passed" % path)
+        return
     open(path, "w").write("\n".join(lines) + "\n")
     print("wrote %s: four full rounds %d / %d instructions (%d / %d slots), 22 partial rounds %d (%d); %d random cases raised the sticky flag"
           % (path, len(texts[0]), len(texts[1]), slots[0], slots[1], len(texts[2]), slots[2], flagged))
