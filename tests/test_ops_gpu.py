@@ -83,6 +83,21 @@ def test_txproof_is_the_whole_prove_root(orc):
         st.chain_streams = 3                                  # the three (independent) shrink chains side by side: the same proofs
         root3, _, all3 = ops.prove_root(ops.GenerationInputs(tabs))
         assert (root3 == ref_root).all() and (all3 == ref_all).all()
+        # ... that was with every chain started under the later tables' STARK proofs (the rule for <= 2 calls in flight); upstream's order
+        # in time -- prove(), then the chains side by side -- gives the same words
+        st.chain_overlap = False
+        root3b, _, all3b = ops.prove_root(ops.GenerationInputs(tabs))
+        assert (root3b == ref_root).all() and (all3b == ref_all).all()
+        st.chain_overlap = "auto"
+        # zk_prove_tables_notify itself: table t's words arrive in order, equal to the slices of the finished AllProof; a listener's
+        # exception surfaces after the call
+        from eth_tx_proof_amd import lib as zl
+        got = []
+        pr = zl.prove_tables(st.ctx(), st.config, items, on_table=lambda t, w: got.append((t, w)))
+        assert [t for t, _ in got] == [0, 1, 2] and (pr == ref_all).all()
+        assert all((w == ref).all() for (_, w), ref in zip(got, ops.split_all_proof(st.config, tabs, pr)))
+        with pytest.raises(ZeroDivisionError):
+            zl.prove_tables(st.ctx(), st.config, items, on_table=lambda t, w: 1 // 0)
         st.chain_streams = 1
         # a size no circuits were built for is fatal, as upstream's "Missing preprocessed circuits"
         st.recursion = plonk.SyntheticRecursion(size_shift=-6, threshold=6, seed=2, degree_bits_ranges=[(8, 9)] * 3)
