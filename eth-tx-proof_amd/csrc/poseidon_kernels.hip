@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 3) void fri_leaf_hash_mfma_kernel(const PsdmTa
 template <bool WAVE> __global__ __launch_bounds__(256) void hash_leaves_colmajor_small_kernel(const u64 *__restrict__ cols, size_t stride, u32 n_cols,
                                                                                               size_t n_leaves, u64 *__restrict__ out, u64 force_redo) {
     __shared__ u64 wtab[WAVE ? psdw::TAB_WORDS : 1];
-    if (WAVE) { psdw::fill(wtab); __syncthreads(); }
+    if (WAVE) { psdw::fill<256>(wtab); __syncthreads(); }
     const int lane = threadIdx.x & 63, l = WAVE ? lane : (lane & 15), gb = lane & ~15;
     const size_t leaf = WAVE ? (size_t)blockIdx.x * 4 + (threadIdx.x >> 6) : ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const bool live = leaf < n_leaves;
@@ -254,7 +254,7 @@ template <bool WAVE> __global__ __launch_bounds__(256) void hash_leaves_colmajor
 template <bool WAVE> __global__ __launch_bounds__(256) void fri_leaf_hash_small_kernel(const u64 *__restrict__ re, const u64 *__restrict__ im, size_t n_leaves,
                                                                                        u32 arity, u64 *__restrict__ out, u64 force_redo) {
     __shared__ u64 wtab[WAVE ? psdw::TAB_WORDS : 1];
-    if (WAVE) { psdw::fill(wtab); __syncthreads(); }
+    if (WAVE) { psdw::fill<256>(wtab); __syncthreads(); }
     const int lane = threadIdx.x & 63, l = WAVE ? lane : (lane & 15), gb = lane & ~15;
     const size_t leaf = WAVE ? (size_t)blockIdx.x * 4 + (threadIdx.x >> 6) : ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const bool live = leaf < n_leaves;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void merkle_level_coop_kernel(const u64 *__res
 // levels that no longer give every SIMD a wave anyway
 __global__ __launch_bounds__(256) void merkle_level_wave_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parents, u64 force_redo) {
     __shared__ u64 wtab[psdw::TAB_WORDS];
-    psdw::fill(wtab); __syncthreads();
+    psdw::fill<256>(wtab); __syncthreads();
     const int lane = threadIdx.x & 63;
     const size_t j = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);        // wave-uniform
     if (j >= n_parents) return;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 << (LV - 1)) void merkle_tail_kernel(const u64 *
     constexpr int NW = 1 << (LV - 1);
     __shared__ u64 wtab[psdw::TAB_WORDS];
     __shared__ u64 dig[2][NW * 4];
-    psdw::fill(wtab); __syncthreads();
+    psdw::fill<(64 << (LV - 1))>(wtab); __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;            // w: wave-uniform
     size_t cnt = n_parents;                                              // a multiple of NW (launcher)
     u64 *out = parent;

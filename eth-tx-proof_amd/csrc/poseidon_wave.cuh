@@ -34,8 +34,28 @@ namespace psdw {
 
 constexpr int TAB_WORDS = (12 + 22 + 12 + 9 + 1) * 64;      // 28.5 KB
 
-// all threads of the block copy the two tables into `lds` (TAB_WORDS u64); caller synchronises afterwards
-__device__ __forceinline__ void fill(u64 *lds) {
+// all threads of the block copy the tables into `lds` (TAB_WORDS u64); caller synchronises afterwards.  NT = threads of the block when the
+// caller knows it (64 for the transcript kernel, 256 for the level kernels): the copy is then 16 bytes per thread and step with constant
+// trip counts, i.e. all loads in flight at once -- with the run-time loop a 64-thread block paid 56 dependent load-store steps, 5-6 us
+// of a transcript launch that carries no permutation at all.
+typedef u64 psdw_v2 __attribute__((ext_vector_type(2)));
+template <int NT, int WORDS> __device__ __forceinline__ void copy_tab(u64 *dst, const u64 *src) {
+    constexpr int PAIRS = WORDS / 2;
+#pragma unroll
+    for (int i = 0; i < (PAIRS + NT - 1) / NT; i++) {
+        const int k = i * NT + (int)threadIdx.x;
+        if (k < PAIRS) ((psdw_v2 *)dst)[k] = ((const psdw_v2 *)src)[k];
+    }
+}
+template <int NT = 0> __device__ __forceinline__ void fill(u64 *lds) {
+    if (NT > 0) {
+        copy_tab<NT ? NT : 64, 12 * 64>(lds, PSD_WV_INIT);
+        copy_tab<NT ? NT : 64, 22 * 64>(lds + 12 * 64, PSD_WV_CHAIN);
+        copy_tab<NT ? NT : 64, 12 * 64>(lds + 34 * 64, PSD_WV_MDS);
+        copy_tab<NT ? NT : 64, 9 * 64>(lds + 46 * 64, PSD_WV_RC);
+        copy_tab<NT ? NT : 64, 64>(lds + 55 * 64, PSD_WV_KSUM);
+        return;
+    }
     for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lds[i] = PSD_WV_INIT[i];
     for (int i = threadIdx.x; i < 22 * 64; i += blockDim.x) lds[12 * 64 + i] = PSD_WV_CHAIN[i];
     for (int i = threadIdx.x; i < 12 * 64; i += blockDim.x) lds[34 * 64 + i] = PSD_WV_MDS[i];

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpLi
     DevChallenger *c = &L;
     const int lane = threadIdx.x;
     ChPerm P; P.wave = wave != 0; P.wtab = wtab; P.force_redo = force_redo;
-    if (P.wave) psdw::fill(wtab);
+    if (P.wave) psdw::fill<64>(wtab);
     {
         const u64 *src = (const u64 *)gc; u64 *dst = (u64 *)c;
         for (u32 i = lane; i < sizeof(DevChallenger) / 8; i += 64) dst[i] = src[i];

@@ -258,18 +258,19 @@ def main():
         f.write(c_array("PSD_PR_D", [x for row in dmat for x in row], per_line=11, qual="PSD_CONST"))
         f.write("#define PSD_M00 %dULL\n" % m00)
         # wave-wide permutation (poseidon_wave.cuh): see derive_wave()
-        f.write(c_array("PSD_WV_INIT", [x for row in wave[0] for x in row], per_line=8, qual="PSD_CONST"))
-        f.write(c_array("PSD_WV_CHAIN", [x for row in wave[1] for x in row], per_line=8, qual="PSD_CONST"))
+        # (16-byte aligned: poseidon_wave.cuh copies these five into LDS two words at a time)
+        f.write(c_array("PSD_WV_INIT", [x for row in wave[0] for x in row], per_line=8, qual="PSD_CONST __attribute__((aligned(16)))"))
+        f.write(c_array("PSD_WV_CHAIN", [x for row in wave[1] for x in row], per_line=8, qual="PSD_CONST __attribute__((aligned(16)))"))
         # MDS rows per lane: out_l = sum_i PSD_WV_MDS[i][l] * s_i (zero rows for the idle lanes l >= 12)
         mds = [[(S.MDS_CIRC[(i - l) % 12] + (S.MDS_DIAG[0] if i == 0 and l == 0 else 0)) if l < 12 else 0 for l in range(64)] for i in range(12)]
         Mfull = S.mds_matrix()
         assert all(mds[i][l] == Mfull[l][i] for i in range(12) for l in range(12)) and all(S.MDS_DIAG[i] == 0 for i in range(1, 12))
-        f.write(c_array("PSD_WV_MDS", [x for row in mds for x in row], per_line=8, qual="PSD_CONST"))
+        f.write(c_array("PSD_WV_MDS", [x for row in mds for x in row], per_line=8, qual="PSD_CONST __attribute__((aligned(16)))"))
         # per-lane constants of the eight full rounds (rows 0..3: rounds 0..3, rows 4..7: rounds 26..29) and PR_FIRST as row 8
         wrc = [[RC[12 * rnd + l] if l < 12 else 0 for l in range(64)] for rnd in (0, 1, 2, 3, 26, 27, 28, 29)] + [[first[l] if l < 12 else 0 for l in range(64)]]
-        f.write(c_array("PSD_WV_RC", [x for row in wrc for x in row], per_line=8, qual="PSD_CONST"))
+        f.write(c_array("PSD_WV_RC", [x for row in wrc for x in row], per_line=8, qual="PSD_CONST __attribute__((aligned(16)))"))
         # the partial rounds' constants folded into the lanes' starting values (fast path of poseidon_wave.cuh): see wave_ksum()
-        f.write(c_array("PSD_WV_KSUM", wave_ksum(wave), per_line=8, qual="PSD_CONST"))
+        f.write(c_array("PSD_WV_KSUM", wave_ksum(wave), per_line=8, qual="PSD_CONST __attribute__((aligned(16)))"))
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     with open(os.path.join(ROOT, "tests", "golden", "poseidon_rc.json"), "w") as f:
         json.dump({"sha256_le_u64": hashlib.sha256(b"".join(struct.pack("<Q", c) for c in RC)).hexdigest(),
