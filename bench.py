@@ -259,7 +259,7 @@ def golden_digest(log_n, n_cols, n_helpers, seed):
     return None
 
 
-def live_pmc_bytes(log_n, n_cols, timeout_s=150):
+def live_pmc_bytes(log_n, n_cols, timeout_s=90):
     """HBM bytes of ONE leaf-hash launch from the PMC counters, collected NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: each in
     a run of its own with --kernel-trace only, as the pool requires) over a child process that commits one n_cols-column 2^log_n-row batch
     (tools/commit_bench.py: the very leaf-hash launch of the bench's unit).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
