@@ -365,15 +365,16 @@ int32_t zk_ntt_lde(zk_ctx *ctx, const u64 *coeffs, size_t in_stride, u64 *lde, s
             p.k = log_n; p.W = W; p.S = S; p.n_cols = n_cols; p.cs_bits = rate_bits;
             p.tw_digit = zk_digit_twiddles(ctx, W, 0); p.tw_full = zk_full_digit_table(ctx, W, 0);
             if (S > 0) { TwoLevel t = zk_root_table(ctx, W + S, 0); p.twA = t.A; p.twB = t.B; }
+            NttCosetPre cpre = {};
             if (i == 0) {
                 for (u32 h = 0; h < P; h++) {
                     TwoLevel pre = zk_scale_table(ctx, gl_mul(GL_GEN, gl_pow(wL, bitrev_u32(h, rate_bits))), 1, log_n);
-                    p.cs_preA[h] = pre.A; p.cs_preB[h] = pre.B;
+                    cpre.A[h] = pre.A; cpre.B[h] = pre.B;
                 }
                 p.pre_bitrev = 1;
             }
             p.permute_out = last ? 1 : 0;
-            if (!zk_ntt_fast_pass(ctx, p, true, row, row ? "ntt_dit_row" : "ntt_dit_tile")) rc = ctx->fail(ZK_ERR_OOM, "ntt_lde: merged pass not launched");
+            if (!zk_ntt_fast_pass(ctx, p, true, row, row ? "ntt_dit_row" : "ntt_dit_tile", i == 0 ? &cpre : nullptr)) rc = ctx->fail(ZK_ERR_OOM, "ntt_lde: merged pass not launched");
             S += W;
         }
         if (mid) ctx->release(mid);

@@ -41,10 +41,10 @@ static const u64 *pass_table(zk_ctx *ctx, const PassParams &p, bool dit, bool st
     return t;
 }
 // the input factors of a coset-merged first pass: slice h = the table the pass would use for the input scale of slot h
-static const u64 *pass_table_cosets(zk_ctx *ctx, const PassParams &p, bool dit) {
+static const u64 *pass_table_cosets(zk_ctx *ctx, const PassParams &p, bool dit, const NttCosetPre &pre) {
     if (p.k > 20) return nullptr;
     char key[256];
-    snprintf(key, sizeof key, "cs.%d.%d.%d.%d.%d.%p.%p.%d", p.k, p.W, p.S, (int)dit, p.cs_bits, (const void *)p.cs_preA[0], (const void *)p.cs_preA[1], p.pre_bitrev);
+    snprintf(key, sizeof key, "cs.%d.%d.%d.%d.%d.%p.%p.%d", p.k, p.W, p.S, (int)dit, p.cs_bits, (const void *)pre.A[0], (const void *)pre.A[1], p.pre_bitrev);
     auto &cache = ctx->table_cache;
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
@@ -53,15 +53,14 @@ static const u64 *pass_table_cosets(zk_ctx *ctx, const PassParams &p, bool dit) 
     if (!t) return nullptr;
     for (u32 h = 0; h < (1u << p.cs_bits); h++) {
         PassParams q = p;
-        q.preA = p.cs_preA[h]; q.preB = p.cs_preB[h];
-        for (int i = 0; i < 16; i++) q.cs_preA[i] = q.cs_preB[i] = nullptr;
+        q.preA = pre.A[h]; q.preB = pre.B[h];
         ZK_LAUNCH(ctx, "ntt_build_table", build_pass_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, (int)dit, 0, t + (size_t)h * n);
     }
     cache[key] = t;
     return t;
 }
 
-bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, const char *name) {
+bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, const char *name, const NttCosetPre *cs_pre) {
     if (p0.W < 4 || p0.W > (row ? 12 : 10) || !p0.tw_full || p0.k > 30) return false;
     if (!row && p0.S < 13 - p0.W) return false;            // a TILE pass needs 2^(13-W) adjacent positions: smaller transforms take the LDS radix-2 kernel
     const size_t vcols = (size_t)p0.n_cols << p0.cs_bits;
@@ -70,7 +69,7 @@ bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, con
     PassParams p = p0;
     p.TL = 13 - p.W;                                        // fixed tile shape (ROW tiles past the last row are skipped inside the kernel)
     p.force_redo = (int)ctx->force_redo;
-    bool need_load = p.preA || p.cs_preA[0] || (dit && p.S > 0);
+    bool need_load = p.preA || cs_pre || (dit && p.S > 0);
     bool need_store = !p.permute_out && ((!dit && p.S > 0) || p.postA || p.post_const);
     // the DIT post table is indexed by the natural output index, which equals the output position only when not permuting
     static const int use_tab = getenv("ZK_NTT_TAB") ? atoi(getenv("ZK_NTT_TAB")) : 3;       // bit0: ROW passes, bit1: TILE passes
@@ -78,7 +77,7 @@ bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, con
     bool tab_on = row ? (use_tab & 1) : (use_tab & 2);
     if (p.cs_bits) {
         // per-slot input factors live in one table of 2^cs_bits slices (the kernel has no two-level path for them)
-        if (p.cs_preA[0]) { p.load_tab = pass_table_cosets(ctx, p, dit); p.tab_sub = (size_t)1 << p.k; if (!p.load_tab) return false; }
+        if (cs_pre) { p.load_tab = pass_table_cosets(ctx, p, dit, *cs_pre); p.tab_sub = (size_t)1 << p.k; if (!p.load_tab) return false; }
         else if (need_load) { p.load_tab = pass_table(ctx, p, dit, false); p.tab_sub = 0; if (!p.load_tab) return false; }
     } else if (need_load && tab_on) p.load_tab = pass_table(ctx, p, dit, false);
     if (need_store && tab_on) p.store_tab = pass_table(ctx, p, dit, true);
@@ -91,7 +90,6 @@ bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, con
         const size_t tiles_per_col = (((size_t)1 << p.k) >> p.W) >> p.TL, blocks = tiles_per_col * vcols;
         if (xcd_pair && p.TL < 4 && p.S > p.TL && (tiles_per_col % 2) == 0 && (blocks % 16) == 0) p.col_fast = 2;
     }
-    for (int i = 0; i < 16; i++) p.cs_preA[i] = p.cs_preB[i] = nullptr;       // host-side fields: keep the kernel argument deterministic
     if (p.cs_bits) return zk_ntt_fast_launch_dit_cs(ctx, p, row, name);
     if (dit) return zk_ntt_fast_launch_dit(ctx, p, row, name);
     return zk_ntt_fast_launch_dif(ctx, p, row, name);

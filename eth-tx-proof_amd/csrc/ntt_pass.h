@@ -26,12 +26,13 @@ struct PassParams {
     // virtual column v = (column v >> cs_bits, slot v & mask) sits at column * stride + slot * sub; its factors at load_tab + slot * tab_sub
     int cs_bits;
     size_t in_sub, out_sub, tab_sub;
-    const u64 *cs_preA[16], *cs_preB[16];   // host side only: the input scale table of every slot (zk_ntt_fast_pass folds them into load_tab)
 };
 
 __device__ __forceinline__ u64 tab2(const u64 *A, const u64 *B, u32 x) { return gl_mul(A[x & 2047], B[x >> 11]); }
 
 
 // register-radix pass (ntt_fast.hip); returns false when the shape is not covered (caller falls back to the LDS radix-2 kernel)
-bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p, bool dit, bool row, const char *name);
+// cs_pre (coset-merged first pass only): the input scale table of every coset slot, folded into one load table of 2^cs_bits slices
+struct NttCosetPre { const u64 *A[16], *B[16]; };
+bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p, bool dit, bool row, const char *name, const NttCosetPre *cs_pre = nullptr);
 u64 *zk_full_digit_table(zk_ctx *ctx, int W, int inverse);
