@@ -216,10 +216,17 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
     return ZK_OK;
 }
 
+int32_t zk_ctx_set_side_commit(zk_ctx *c, int32_t on) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    c->side_commit = on ? 1 : 0;
+    return ZK_OK;
+}
+
 int32_t zk_ctx_destroy(zk_ctx *c) {
     if (!c) return ZK_ERR_INVALID_ARG;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->side) { zk_ctx_destroy(c->side); c->side = nullptr; }
     c->prof_flush();
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (!c->efence) for (auto &kv : c->block_size) hipFree(kv.first);

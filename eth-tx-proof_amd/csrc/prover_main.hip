@@ -215,6 +215,19 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
     // per-kernel labels of the profiler: "phase: ..." entries of zk_profile_get)
     { TOpList a = {}; a.n = 1; a.op[0].kind = TOP_INIT; zk_transcript_run(ctx, ch, a); }
     std::unique_ptr<ProfScope> phase(new ProfScope(ctx, "phase: compute all trace commitments"));
+    // zk_ctx_set_side_commit: which table (the one with the most cells) commits on the side context
+    u32 side_t = 0xFFFFFFFFu;
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
+    if (ctx->side_commit && nt >= 2) {
+        if (!ctx->side && zk_ctx_create(ctx->device, nullptr, &ctx->side) != ZK_OK) ctx->side = nullptr;
+        if (ctx->side && hipEventCreateWithFlags(&side_ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&side_ev[1], hipEventDisableTiming) == hipSuccess) {
+            size_t best = 0;
+            for (u32 t = 0; t < nt; t++) {
+                const size_t cells = (size_t)tables[t].air->n_trace_cols << tables[t].log_n;
+                if (cells > best) { best = cells; side_t = t; }
+            }
+        }
+    }
     for (u32 t = 0; t < nt && rc == ZK_OK; t++) {
         const size_t n = (size_t)1 << tables[t].log_n;
         const u32 C = tables[t].air->n_trace_cols;
@@ -227,15 +240,25 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
             if ((rc = ctx->upload_large(d, tables[t].trace, n * C * sizeof(u64), ctx->stream)) != ZK_OK) break;
             d_trace[t] = d;
         }
-        rc = zk_batch_commit_dev(ctx, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);
+        if (t == side_t) {
+            // the widest table on the side context: its stream starts behind what this stream has enqueued so far (the trace itself),
+            // its commitment joins this stream again where its cap is observed
+            if (hipEventRecord(side_ev[0], ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->side->stream, side_ev[0], 0) != hipSuccess) { rc = ctx->fail(ZK_ERR_HIP, "prove: side stream"); break; }
+            rc = zk_batch_commit_dev(ctx->side, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);
+            if (rc == ZK_OK && hipEventRecord(side_ev[1], ctx->side->stream) != hipSuccess) rc = ctx->fail(ZK_ERR_HIP, "prove: side stream");
+        } else rc = zk_batch_commit_dev(ctx, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);
         if (rc) break;
+    }
+    for (u32 t = 0; t < nt && rc == ZK_OK; t++) {
+        if (t == side_t && hipStreamWaitEvent(ctx->stream, side_ev[1], 0) != hipSuccess) { rc = ctx->fail(ZK_ERR_HIP, "prove: side stream"); break; }
         scratch_probe(ctx, d_zeta + 7);
         ZK_LAUNCH(ctx, "copy_words", copy_words2_kernel, g1(capw), dim3(256), 0, trace_b[t]->cap(), d_proof + lay[t].o_trace_cap, capw);
         TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + lay[t].o_trace_cap; a.op[0].n = capw;
         zk_transcript_run(ctx, ch, a);
     }
     phase.reset();
-    if (rc) return rc;
+    for (int i = 0; i < 2; i++) if (side_ev[i]) hipEventDestroy(side_ev[i]);
+    if (rc) { if (side_t != 0xFFFFFFFFu) hipStreamSynchronize(ctx->side->stream); return rc; }
     for (u32 t = 0; t < nt; t++) if (tables[t].air->n_public_inputs) {
         TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_pub[t]; a.op[0].n = tables[t].air->n_public_inputs;
         zk_transcript_run(ctx, ch, a);

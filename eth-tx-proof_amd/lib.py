@@ -72,6 +72,10 @@ class Context:
             self.h = None
             raise ZkError(rc, "zk_ctx_create")
 
+    def set_side_commit(self, on):
+        """zk_ctx_set_side_commit: the widest table's trace commitment of a multi-table proof on a second stream (latency switch)"""
+        self._chk(lib().zk_ctx_set_side_commit(self.h, C.c_int32(1 if on else 0)), "zk_ctx_set_side_commit")
+
     def _chk(self, rc, what):
         if rc:
             raise ZkError(rc, what, lib().zk_last_error(self.h).decode())

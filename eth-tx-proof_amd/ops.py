@@ -217,6 +217,7 @@ def prove_root(input: "GenerationInputs", timing: Optional[dict] = None):
 
 def _prove_root(st, rc, ctx, input, timing, overlap):
     t0 = time.time()
+    ctx.set_side_commit(overlap)          # the same rule for the other latency device: the widest table's trace commitment on a second stream
     try:            # by_table[t].by_stark_size[degree_bits]: a size without circuits is an error whatever else happens
         chains = [rc.shrink_chain(ti, t.air, t.log_n) for ti, t in enumerate(input.tables)]
     except KeyError as e:

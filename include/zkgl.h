@@ -50,6 +50,11 @@ typedef struct zk_challenger zk_challenger; /* device-resident Challenger<F, Pos
 /* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to create a private one. */
 int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out);
 int32_t zk_ctx_destroy(zk_ctx *ctx);
+/* Latency switch of zk_prove_tables for proofs of several tables (default off): the trace commitment of the table with the most cells --
+ * for the zkEVM's shapes a hash of hundreds of permutations per leaf over few leaves, i.e. one wave per SIMD -- runs on a second stream
+ * beside the other tables' commitments (they are independent until their caps are observed, in table order, afterwards).  Same proof.
+ * One transaction alone gains a few milliseconds; with the chip saturated by other proofs there is nothing to gain. */
+int32_t zk_ctx_set_side_commit(zk_ctx *ctx, int32_t on);
 int32_t zk_ctx_synchronize(zk_ctx *ctx);
 const char *zk_last_error(zk_ctx *ctx);
 /* returns the hipStream_t the ctx enqueues on (for callers that record their own HIP events) */
