@@ -187,6 +187,22 @@ void zk_ctx::prof_flush() {
     }
 }
 
+// zk_trace_upload_packed: column j of the packed buffer (width 1 / 2 / 4 / 8 bytes per row, little-endian) -> column j of the usual u64 layout
+__global__ void trace_widen_kernel(const unsigned char *__restrict__ packed, const u64 *__restrict__ off, size_t n, u64 *__restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const u32 j = blockIdx.y;
+    const u64 o = off[j];
+    const u32 w = (u32)(o >> 56);
+    const unsigned char *src = packed + (o & 0x00FFFFFFFFFFFFFFull);
+    u64 v;
+    if (w == 1) v = src[r];
+    else if (w == 2) v = ((const uint16_t *)src)[r];
+    else if (w == 4) v = ((const uint32_t *)src)[r];
+    else v = gl_canon(((const u64 *)src)[r]);
+    out[(size_t)j * n + r] = v;
+}
+
 extern "C" {
 
 int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
@@ -316,6 +332,32 @@ int32_t zk_trace_upload_async(zk_ctx *c, const uint64_t *trace, size_t n_words, 
     if (rc != ZK_OK) { if (done) c->event_pool.push_back(done); hipStreamSynchronize(c->copy_stream); c->release(d); return rc; }
     c->pending_uploads.emplace_back(d, done);
     *d_ptr = (uint64_t *)d;
+    return ZK_OK;
+}
+int32_t zk_trace_upload_packed(zk_ctx *c, const void *packed, uint32_t log_n, uint32_t n_cols, const uint8_t *col_bytes, uint64_t **d_ptr) {
+    if (!c || !packed || !col_bytes || !d_ptr || n_cols == 0 || n_cols > ZK_PACKED_MAX_COLS || log_n > 28) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    *d_ptr = nullptr;
+    const size_t n = (size_t)1 << log_n;
+    std::vector<u64> off(n_cols + 1, 0);                     // byte offset of every column in the packed buffer | its width in the top byte
+    size_t total = 0;
+    for (u32 j = 0; j < n_cols; j++) {
+        const u32 w = col_bytes[j];
+        if (w != 1 && w != 2 && w != 4 && w != 8) return c->fail(ZK_ERR_INVALID_ARG, "upload_packed: column width must be 1, 2, 4 or 8 bytes");
+        total = (total + w - 1) / w * w;                     // every column starts at a multiple of its element size
+        off[j] = (u64)total | ((u64)w << 56);
+        total += n * w;
+    }
+    u64 *d = (u64 *)c->alloc(n * n_cols * sizeof(u64));
+    unsigned char *d_packed = (unsigned char *)c->alloc(total);
+    u64 *d_off = (u64 *)c->alloc((size_t)n_cols * sizeof(u64));
+    if (!d || !d_packed || !d_off) { c->release(d); c->release(d_packed); c->release(d_off); return c->fail(ZK_ERR_OOM, "upload_packed: device memory"); }
+    int32_t rc = c->upload_large(d_packed, packed, total, c->stream);
+    if (rc == ZK_OK) rc = c->upload_small(d_off, off.data(), (size_t)n_cols * sizeof(u64));
+    if (rc == ZK_OK) ZK_LAUNCH(c, "trace_widen", trace_widen_kernel, dim3((unsigned)((n + 255) / 256), n_cols), dim3(256), 0, (const unsigned char *)d_packed, (const u64 *)d_off, n, d);
+    c->release(d_packed); c->release(d_off);                 // stream-ordered
+    if (rc != ZK_OK) { c->release(d); return rc; }
+    *d_ptr = d;
     return ZK_OK;
 }
 int32_t zk_dev_upload(zk_ctx *c, void *d_dst, const void *src, size_t bytes) {

@@ -72,6 +72,26 @@ class Context:
             self.h = None
             raise ZkError(rc, "zk_ctx_create")
 
+    def upload_packed(self, columns):
+        """zk_trace_upload_packed: `columns` = list of 1-D numpy arrays (uint8 / uint16 / uint32 / uint64, one per trace column, equal
+        lengths 2^k) -> device pointer of the widened n_cols x n uint64 trace (zk_dev_free / dev_free it after the proof)"""
+        n = len(columns[0])
+        log_n = n.bit_length() - 1
+        assert n == 1 << log_n and all(len(c) == n for c in columns)
+        widths = np.array([np.dtype(c.dtype).itemsize for c in columns], dtype=np.uint8)
+        buf, at = bytearray(), 0
+        for c, w in zip(columns, widths):
+            w = int(w)
+            pad = (-at) % w
+            buf += b"\0" * pad + np.ascontiguousarray(c).tobytes()
+            at += pad + n * w
+        raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+        p = C.c_void_p()
+        self._chk(lib().zk_trace_upload_packed(self.h, raw.ctypes.data_as(C.c_void_p), C.c_uint32(log_n), C.c_uint32(len(columns)),
+                                                widths.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(p)), "zk_trace_upload_packed")
+        self.synchronize()               # `raw` is a temporary: the (pageable) source must outlive the staged copy
+        return p.value
+
     def set_side_commit(self, on):
         """zk_ctx_set_side_commit: the widest table's trace commitment of a multi-table proof on a second stream (latency switch)"""
         self._chk(lib().zk_ctx_set_side_commit(self.h, C.c_int32(1 if on else 0)), "zk_ctx_set_side_commit")

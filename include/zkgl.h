@@ -87,6 +87,14 @@ int32_t zk_host_free(zk_ctx *ctx, void *h_ptr);
  * that one, so a prefetch of the unit after next never holds a proof back.  Call it BEFORE the zk_prove_tables of the current
  * unit so that the copy overlaps that proof. */
 int32_t zk_trace_upload_async(zk_ctx *ctx, const uint64_t *trace, size_t n_words, uint64_t **d_ptr);
+/* A trace with NARROW columns over PCIe: column j of `packed` holds its n = 2^log_n rows in col_bytes[j] bytes each (1, 2, 4 or 8,
+ * little-endian, unsigned; every column starts at the next multiple of its element size after the previous one); the device widens to
+ * the usual n_cols x n uint64 layout in memory owned by the context (zk_dev_free it after the proof; pass it with trace_on_device = 1).
+ * Most columns of the zkEVM's tables are flags, bytes and 16 / 32-bit limbs: their traces cross the link 2-6 x smaller this way (on hosts
+ * with 21-24 GB/s links the unit proof is link-bound from host-resident 64-bit traces).  Enqueued on the context's
+ * stream; returns at once for a pinned source. */
+#define ZK_PACKED_MAX_COLS 65535u
+int32_t zk_trace_upload_packed(zk_ctx *ctx, const void *packed, uint32_t log_n, uint32_t n_cols, const uint8_t *col_bytes, uint64_t **d_ptr);
 
 /* ------------------------------------------------------------------ field / NTT
  * plonky2_field::fft::{fft_with_options, ifft_with_options}, PolynomialCoeffs::coset_fft_with_options,

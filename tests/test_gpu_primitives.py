@@ -337,3 +337,26 @@ def test_small_commit_kernels_equal_thread_per_leaf_and_oracle(zk, orc, monkeypa
             b.free()
         finally:
             c2.close()
+
+
+def test_packed_trace_upload_widens_to_the_u64_layout(ctx):
+    """zk_trace_upload_packed: columns of 1 / 2 / 4 / 8 bytes per row cross PCIe narrow and come out as the usual n_cols x n uint64 trace
+    (8-byte columns canonicalised like every trace that enters); odd column orders exercise the alignment rule of the packed buffer."""
+    rng = np.random.default_rng(11)
+    n = 1 << 9
+    cols = [rng.integers(0, 2, n).astype(np.uint8),                       # a flag
+            rng.integers(0, 1 << 16, n).astype(np.uint16),
+            rng.integers(0, 256, n).astype(np.uint8),
+            rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32),
+            rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1),     # full width, some values >= p
+            rng.integers(0, 256, n).astype(np.uint8),
+            rng.integers(0, 1 << 63, n, dtype=np.uint64)]
+    cols[4][:3] = [0xFFFFFFFF00000001, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF00000000]
+    d = ctx.upload_packed(cols)
+    got = ctx.download(d, (len(cols), n))
+    ctx.dev_free(d)
+    P = np.uint64(0xFFFFFFFF00000001)
+    for j, c in enumerate(cols):
+        want = c.astype(np.uint64)
+        want = np.where(want >= P, want - P, want)
+        assert (got[j] == want).all(), j
