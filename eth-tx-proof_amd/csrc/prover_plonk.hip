@@ -558,8 +558,10 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
                     ProfScope ps(ctx, "plonk_quotient");
                     if (ctx->sync_launch) fprintf(stderr, "[zk %p] plonk_quotient (compiled gate program, %s, kernel %zu of %zu) grid %u\n", (void *)ctx,
                                                   st->gates_fn_is_module ? "hiprtc" : "build-time", kk + 1, st->gates_fns.size(), (unsigned)((L + 255) / 256));
-                    if (st->gates_fn_is_module) e = hipModuleLaunchKernel((hipFunction_t)st->gates_fns[kk], (unsigned)((L + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
-                    else e = hipLaunchKernel(st->gates_fns[kk], g1(L), dim3(256), args, 0, ctx->stream);
+                    // kernel 0 (the permutation part) spreads a point's (challenge, chunk) pairs over 8 threads: 32 points per workgroup
+                    const unsigned grid = kk == 0 ? (unsigned)((L + 31) / 32) : (unsigned)((L + 255) / 256);
+                    if (st->gates_fn_is_module) e = hipModuleLaunchKernel((hipFunction_t)st->gates_fns[kk], grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+                    else e = hipLaunchKernel(st->gates_fns[kk], dim3(grid), dim3(256), args, 0, ctx->stream);
                     if (e != hipSuccess) rc = ctx->fail(ZK_ERR_HIP, "plonk quotient: launch of a compiled gate kernel failed");
                     if (ctx->sync_launch) hipStreamSynchronize(ctx->stream);
                 }

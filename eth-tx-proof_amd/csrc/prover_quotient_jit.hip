@@ -226,7 +226,7 @@ static const char PLK_PARAMS_SRC[] =
 #define PLK_SEG 768u
 #define PLK_SEG_SLACK 192u
 #define PLK_FENCE 64u
-#define PLK_GEN_VERSION 7u
+#define PLK_GEN_VERSION 8u
 
 // where the program is cut and which registers cross each cut
 struct PlkPlan { std::vector<u32> cut; std::vector<std::vector<u32>> live; u32 max_live = 0; };   // segment k = [cut[k], cut[k+1]); live[k]: registers alive at cut[k+1]
@@ -351,26 +351,33 @@ static std::string generate_plonk(const zk_air *air, u32 W, u32 NC, u32 nch, u32
     if (n_kernels) *n_kernels = K + 1;
     if (n_state) *n_state = nch + pl.max_live;
     // kernel 0: the permutation part [L_0 (Z - 1)] [partial-product checks] -- the loop code of the interpreter kernel, with its
-    // arithmetic (canonical gl_mul: no sticky word carried around loops), accumulators to the state buffer
+    // arithmetic (canonical gl_mul: no sticky word carried around loops), accumulators to the state buffer.  32 points x 8 slots per
+    // workgroup: a slot takes every eighth (challenge, chunk) pair of its point (at most three of the twenty: 24 wires instead of 160
+    // dependent column loads per thread; slot 0 also the L_0 terms), the partial sums meet in LDS.  Launched with ceil(L / 32) workgroups.
     appendf(s, "extern \"C\" __global__ __launch_bounds__(256) void %s_0(PlkQuotParams p) {\n", kname);
-    s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
+    appendf(s, "    __shared__ u64 part[%u][8][32];\n", nch);
+    s += "    const u32 pl = threadIdx.x & 31, slot = threadIdx.x >> 5;\n    const u64 s = (u64)blockIdx.x * 32 + pl;\n    const bool live = s < p.L;\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = 0;\n", j);
+    s += "    if (live) {\n";
     s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n    const u64 sn = bitrev_u32((i + p.qdf) & (u32)(p.L - 1), p.lgL);\n";
     s += "    const u64 x = gl_mul(p.xA[i & 2047], p.xB[i >> 11]);\n";
-    for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = 0;\n", j);
-    s += "    const u32 npp = p.nchunks - 1;\n    const u64 l0v = p.l0[s];\n    u32 ti = 0;\n";
-    s += "    for (u32 ci = 0; ci < p.nch; ci++, ti++) { const u64 t = gl_mul(l0v, gl_sub(p.z_lde[(u64)ci * p.L + s], 1));\n";
+    s += "    const u32 npp = p.nchunks - 1, G = p.nch * p.nchunks;\n";
+    s += "    if (slot == 0) { const u64 l0v = p.l0[s];\n      for (u32 ci = 0; ci < p.nch; ci++) { const u64 t = gl_mul(l0v, gl_sub(p.z_lde[(u64)ci * p.L + s], 1));\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "        acc%u = gl_mul_add(t, p.apow[%uull * p.NT + ci], acc%u);\n", j, j, j);
+    s += "      } }\n";
+    s += "    for (u32 g = slot; g < G; g += 8) {\n        const u32 ci = g / p.nchunks, c = g % p.nchunks, ti = p.nch + g;\n        const u64 beta = p.bg[ci], gamma = p.bg[p.nch + ci];\n";
+    s += "        u64 num = 1, den = 1;\n        for (u32 u = 0; u < p.qdf; u++) {\n            const u32 j = c * p.qdf + u;\n            const u64 w = p.w_lde[(u64)j * p.L + s];\n";
+    s += "            num = gl_mul(num, gl_add(gl_add(w, gl_mul(beta, gl_mul(p.kis[j], x))), gamma));\n";
+    s += "            den = gl_mul(den, gl_add(gl_add(w, gl_mul(beta, p.cs_lde[(u64)(p.NC + j) * p.L + s])), gamma));\n        }\n";
+    s += "        const u64 prev = c == 0 ? p.z_lde[(u64)ci * p.L + s] : p.z_lde[((u64)p.nch + (u64)ci * npp + c - 1) * p.L + s];\n";
+    s += "        const u64 next = c == p.nchunks - 1 ? p.z_lde[(u64)ci * p.L + sn] : p.z_lde[((u64)p.nch + (u64)ci * npp + c) * p.L + s];\n";
+    s += "        const u64 t = gl_sub(gl_mul(prev, num), gl_mul(next, den));\n";
     for (u32 j = 0; j < nch; j++) appendf(s, "        acc%u = gl_mul_add(t, p.apow[%uull * p.NT + ti], acc%u);\n", j, j, j);
-    s += "    }\n";
-    s += "    for (u32 ci = 0; ci < p.nch; ci++) {\n        const u64 beta = p.bg[ci], gamma = p.bg[p.nch + ci];\n        for (u32 c = 0; c < p.nchunks; c++, ti++) {\n";
-    s += "            u64 num = 1, den = 1;\n            for (u32 u = 0; u < p.qdf; u++) {\n                const u32 j = c * p.qdf + u;\n                const u64 w = p.w_lde[(u64)j * p.L + s];\n";
-    s += "                num = gl_mul(num, gl_add(gl_add(w, gl_mul(beta, gl_mul(p.kis[j], x))), gamma));\n";
-    s += "                den = gl_mul(den, gl_add(gl_add(w, gl_mul(beta, p.cs_lde[(u64)(p.NC + j) * p.L + s])), gamma));\n            }\n";
-    s += "            const u64 prev = c == 0 ? p.z_lde[(u64)ci * p.L + s] : p.z_lde[((u64)p.nch + (u64)ci * npp + c - 1) * p.L + s];\n";
-    s += "            const u64 next = c == p.nchunks - 1 ? p.z_lde[(u64)ci * p.L + sn] : p.z_lde[((u64)p.nch + (u64)ci * npp + c) * p.L + s];\n";
-    s += "            const u64 t = gl_sub(gl_mul(prev, num), gl_mul(next, den));\n";
-    for (u32 j = 0; j < nch; j++) appendf(s, "            acc%u = gl_mul_add(t, p.apow[%uull * p.NT + ti], acc%u);\n", j, j, j);
-    s += "        }\n    }\n";
-    for (u32 j = 0; j < nch; j++) appendf(s, "    p.state[%uull * p.L + s] = acc%u;\n", j, j);
+    s += "    }\n    }\n";
+    for (u32 j = 0; j < nch; j++) appendf(s, "    part[%u][slot][pl] = acc%u;\n", j, j);
+    s += "    __syncthreads();\n";
+    appendf(s, "    if (slot < %uu && live) { u64 a = part[slot][0][pl];\n", nch);
+    s += "        for (int q = 1; q < 8; q++) a = gl_add(a, part[slot][q][pl]);\n        p.state[(u64)slot * p.L + s] = a; }\n";
     s += "}\n";
     u32 seq = 0;
     for (u32 k = 0; k < K; k++) {
