@@ -175,7 +175,7 @@ int32_t zk_eval_cols_multi(zk_ctx *ctx, int k, u32 n_jobs, const zk_eval_job *jo
     const u32 ntab = (1u << g.LT) + (1u << g.LI) + (1u << g.LB);
     u64 *tab = (u64 *)ctx->alloc((size_t)ntab * m.n_points * 2 * sizeof(u64));
     u64 *partial = (u64 *)ctx->alloc(((size_t)total << g.LB) * 2 * sizeof(u64));
-    if (!tab || !partial) return ZK_ERR_OOM;
+    if (!tab || !partial) { ctx->release(tab); ctx->release(partial); return ctx->fail(ZK_ERR_OOM, "eval_cols_multi: device memory"); }
     ZK_LAUNCH(ctx, "eval_tables", eval_tables_multi_kernel, dim3((ntab + 255) / 256, m.n_points), dim3(256), 0, m, g, ntab, tab);
     ZK_LAUNCH(ctx, "eval_cols", eval_cols_multi_kernel, dim3(1u << g.LB, total), dim3(256), 0, m, g, ntab, (const u64 *)tab, partial);
     ZK_LAUNCH(ctx, "eval_reduce", eval_reduce_multi_kernel, dim3((total + 255) / 256), dim3(256), 0, m, (const u64 *)partial, g.LB, (u64 *)nullptr);
@@ -188,7 +188,7 @@ int32_t zk_eval_cols_at(zk_ctx *ctx, const u64 *coeffs, size_t stride, int k, in
     u32 ntab = (1u << g.LT) + (1u << g.LI) + (1u << g.LB);
     u64 *tab = (u64 *)ctx->alloc((size_t)ntab * 2 * sizeof(u64));
     u64 *partial = (u64 *)ctx->alloc(((size_t)n_cols << g.LB) * 2 * sizeof(u64));
-    if (!tab || !partial) return ZK_ERR_OOM;
+    if (!tab || !partial) { ctx->release(tab); ctx->release(partial); return ctx->fail(ZK_ERR_OOM, "eval_cols_at: device memory"); }
     ZK_LAUNCH(ctx, "eval_tables", eval_tables_kernel, dim3((ntab + 255) / 256), dim3(256), 0, d_point, g, tab);
     ZK_LAUNCH(ctx, "eval_cols", eval_cols_kernel, dim3(1u << g.LB, n_cols), dim3(256), 0, coeffs, stride, g, (const u64 *)tab, partial);
     ZK_LAUNCH(ctx, "eval_reduce", eval_reduce_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, (const u64 *)partial, g.LB, n_cols, d_out);

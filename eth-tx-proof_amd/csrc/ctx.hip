@@ -249,6 +249,8 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     hipFree(c->d_err);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_out) hipHostFree(c->h_out);
+    if (c->h_packed_off) hipHostFree(c->h_packed_off);
+    if (c->packed_off_done) hipEventDestroy(c->packed_off_done);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 3; i++) if (c->part_stream[i]) { hipStreamSynchronize(c->part_stream[i]); hipStreamDestroy(c->part_stream[i]); }
     for (auto &pe : c->pending_uploads) hipEventDestroy(pe.second);
@@ -267,18 +269,32 @@ int32_t zk_ctx_synchronize(zk_ctx *c) {
 const char *zk_last_error(zk_ctx *c) { return c ? c->last_error.c_str() : "null ctx"; }
 void *zk_ctx_stream(zk_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-int32_t zk_profile_enable(zk_ctx *c, int32_t on) { if (!c) return ZK_ERR_INVALID_ARG; c->prof = on != 0; return ZK_OK; }
+int32_t zk_profile_enable(zk_ctx *c, int32_t on) { if (!c) return ZK_ERR_INVALID_ARG; c->prof = on != 0; if (c->side) c->side->prof = c->prof; return ZK_OK; }
 int32_t zk_profile_reset(zk_ctx *c) {
     if (!c) return ZK_ERR_INVALID_ARG;
     hipStreamSynchronize(c->stream);
     c->prof_flush();
     c->prof_recs.clear(); c->prof_index.clear();
+    if (c->side) zk_profile_reset(c->side);
     return ZK_OK;
 }
 int32_t zk_profile_count(zk_ctx *c) {
     if (!c) return ZK_ERR_INVALID_ARG;
     hipStreamSynchronize(c->stream);
     c->prof_flush();
+    if (c->side) {
+        // the side context's launches (zk_ctx_set_side_commit) belong to this context's proofs: fold its records into these
+        hipStreamSynchronize(c->side->stream);
+        c->side->prof_flush();
+        for (auto &r : c->side->prof_recs) {
+            auto it = c->prof_index.find(r.name);
+            int idx;
+            if (it == c->prof_index.end()) { idx = (int)c->prof_recs.size(); c->prof_index[r.name] = idx; c->prof_recs.emplace_back(); c->prof_recs.back().name = r.name; }
+            else idx = it->second;
+            c->prof_recs[idx].launches += r.launches; c->prof_recs[idx].total_ms += r.total_ms;
+        }
+        c->side->prof_recs.clear(); c->side->prof_index.clear();
+    }
     return (int32_t)c->prof_recs.size();
 }
 int32_t zk_profile_get(zk_ctx *c, int32_t i, const char **name, uint64_t *launches, double *total_ms) {
@@ -353,7 +369,26 @@ int32_t zk_trace_upload_packed(zk_ctx *c, const void *packed, uint32_t log_n, ui
     u64 *d_off = (u64 *)c->alloc((size_t)n_cols * sizeof(u64));
     if (!d || !d_packed || !d_off) { c->release(d); c->release(d_packed); c->release(d_off); return c->fail(ZK_ERR_OOM, "upload_packed: device memory"); }
     int32_t rc = c->upload_large(d_packed, packed, total, c->stream);
-    if (rc == ZK_OK) rc = c->upload_small(d_off, off.data(), (size_t)n_cols * sizeof(u64));
+    // The offset table does NOT go through the per-proof staging buffer (h_stage): this function returns before its copies have
+    // run, and the next zk_prove_tables / zk_prove_plonk of the context resets h_stage_used and writes its own header words over
+    // the same staging bytes while the copy of d_off is still queued behind the large upload.  It has a pinned buffer
+    // of its own, reused only after the event behind the previous call's copy has completed.
+    if (rc == ZK_OK) {
+        const size_t ob = (size_t)n_cols * sizeof(u64);
+        if (c->h_packed_off_cap < ob) {
+            if (c->h_packed_off) { hipStreamSynchronize(c->stream); hipHostFree(c->h_packed_off); c->h_packed_off = nullptr; c->h_packed_off_cap = 0; }
+            size_t cap = (ob + 4095) & ~(size_t)4095;
+            if (hipHostMalloc((void **)&c->h_packed_off, cap, hipHostMallocDefault) != hipSuccess) { c->h_packed_off = nullptr; rc = c->fail(ZK_ERR_OOM, "upload_packed: pinned offset table"); }
+            else c->h_packed_off_cap = cap;
+        }
+        if (rc == ZK_OK && !c->packed_off_done && hipEventCreateWithFlags(&c->packed_off_done, hipEventDisableTiming) != hipSuccess) { c->packed_off_done = nullptr; rc = c->fail(ZK_ERR_HIP, "upload_packed: event"); }
+        if (rc == ZK_OK && hipEventSynchronize(c->packed_off_done) != hipSuccess) rc = c->fail(ZK_ERR_HIP, "upload_packed: event wait");   // never recorded: returns at once
+        if (rc == ZK_OK) {
+            memcpy(c->h_packed_off, off.data(), ob);
+            if (hipMemcpyAsync(d_off, c->h_packed_off, ob, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipEventRecord(c->packed_off_done, c->stream) != hipSuccess)
+                rc = c->fail(ZK_ERR_HIP, "upload_packed: offset table copy");
+        }
+    }
     if (rc == ZK_OK) ZK_LAUNCH(c, "trace_widen", trace_widen_kernel, dim3((unsigned)((n + 255) / 256), n_cols), dim3(256), 0, (const unsigned char *)d_packed, (const u64 *)d_off, n, d);
     c->release(d_packed); c->release(d_off);                 // stream-ordered
     if (rc != ZK_OK) { c->release(d); return rc; }

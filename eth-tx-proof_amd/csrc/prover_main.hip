@@ -25,6 +25,7 @@ __global__ void zeta_kernel(u64 *zeta /* in: zeta; out: +2 = g_n * zeta */, u32 
     zeta[4] = 1; zeta[5] = 0;
 }
 __global__ void take_re_kernel(const u64 *ext, u32 n, u64 *out) { u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = ext[2 * i]; }
+__global__ void fold_err_word_kernel(u64 *dst, u64 *src) { const u64 e = *src; if (e) { if (!*dst) *dst = e; *src = 0; } }
 __global__ void copy_words2_kernel(const u64 *src, u64 *dst, u32 n) { u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
 
 // Debugging aid (env ZK_DEBUG_SCRATCH_PROBE=1, tools/stress_faults.py): a kernel that deliberately lives in scratch (a dynamically
@@ -244,13 +245,19 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
             // the widest table on the side context: its stream starts behind what this stream has enqueued so far (the trace itself),
             // its commitment joins this stream again where its cap is observed
             if (hipEventRecord(side_ev[0], ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->side->stream, side_ev[0], 0) != hipSuccess) { rc = ctx->fail(ZK_ERR_HIP, "prove: side stream"); break; }
+            ctx->side->prof = ctx->prof;          // its launches are part of this proof's profile (zk_profile_count folds them in)
             rc = zk_batch_commit_dev(ctx->side, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);
             if (rc == ZK_OK && hipEventRecord(side_ev[1], ctx->side->stream) != hipSuccess) rc = ctx->fail(ZK_ERR_HIP, "prove: side stream");
         } else rc = zk_batch_commit_dev(ctx, d_trace[t], tables[t].log_n, C, cfg.rate_bits, cfg.cap_height, 1, &trace_b[t]);
         if (rc) break;
     }
     for (u32 t = 0; t < nt && rc == ZK_OK; t++) {
-        if (t == side_t && hipStreamWaitEvent(ctx->stream, side_ev[1], 0) != hipSuccess) { rc = ctx->fail(ZK_ERR_HIP, "prove: side stream"); break; }
+        if (t == side_t) {
+            if (hipStreamWaitEvent(ctx->stream, side_ev[1], 0) != hipSuccess) { rc = ctx->fail(ZK_ERR_HIP, "prove: side stream"); break; }
+            // device-side checks raised by the side context's kernels land in ITS error word: fold it into this proof's (first error
+            // wins) and clear it, behind the join
+            hipLaunchKernelGGL(fold_err_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_err, ctx->side->d_err);
+        }
         scratch_probe(ctx, d_zeta + 7);
         ZK_LAUNCH(ctx, "copy_words", copy_words2_kernel, g1(capw), dim3(256), 0, trace_b[t]->cap(), d_proof + lay[t].o_trace_cap, capw);
         TOpList a = {}; a.n = 1; a.op[0].kind = TOP_OBSERVE; a.op[0].src = d_proof + lay[t].o_trace_cap; a.op[0].n = capw;

@@ -105,12 +105,14 @@ class ProverInput:
             try:
                 runtime.map(ops.TxProof(), [self.proof_gen_ir[i] for i in mine], indices=mine,                 # .map(&TxProof)
                             on_result=lambda i, p: ho.put(i, p.proof))
-            except ops.FatalError as e:
+            except Exception as e:      # FatalError or anything else: the other ranks must still hear about it
                 failed = e
             try:
                 words = ho.finish(ok=failed is None)
             except sharding.HandoffError as e:
                 raise (failed or ops.FatalError(str(e))) from e
+            if failed is not None:      # finish(ok=False) raises on every rank; kept for a hand-off that says otherwise
+                raise failed
             self.handoff = {"exposed_s": ho.exposed_s, "bytes": ho.bytes}
             if rank != 0:
                 return None

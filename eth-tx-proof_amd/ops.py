@@ -223,14 +223,19 @@ def _prove_root(st, rc, ctx, input, timing, overlap):
     except KeyError as e:
         raise FatalError(str(e.args[0])) from e
     shrunk = [None] * len(input.tables)
+    collect = timing.get("collect") if timing is not None else None      # a list: receives every chain proof as (table, step, words)
 
     def shrink(c, ti, t, words, chain):
         """by_table[ti].by_stark_size[log_n].shrink(stark_proof): initial wrapper, then every shrinking wrapper, on context c"""
         state, wires, pubs = rc.initial_wrapper(c, ti, t.air, t.log_n, words)
         proof = zl.prove_plonk(state, wires, pubs, ctx=c)
+        if collect is not None:
+            collect.append((ti, 0, proof))
         for step in range(1, len(chain)):
             state, wires, pubs = rc.shrinking_wrapper(c, ti, t.air, t.log_n, step, proof)
             proof = zl.prove_plonk(state, wires, pubs, ctx=c)
+            if collect is not None:
+                collect.append((ti, step, proof))
         shrunk[ti] = proof
     k = min(st.chain_streams, len(input.tables))
     if k <= 1 or not overlap:

@@ -116,6 +116,10 @@ class Handoff:
                 dist.send(torch.from_numpy(w.view(np.int64)), self.dst, group=self.group, tag=self.PAY_TAG)
         except Exception as e:          # surfaced by finish()
             self.error = e
+            try:        # rank dst counts markers: one more attempt to say "this rank is out" so that it is not left in recv
+                dist.send(torch.tensor([-1, 0, 0], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
+            except Exception:
+                pass    # transport gone: rank dst runs into the group's timeout (cached_host_group(timeout_s))
 
     def _recv_loop(self):
         try:
@@ -148,15 +152,21 @@ class Handoff:
         if self.rank != self.dst:
             self._q.put((None, bool(ok)))
         self._th.join()
-        if self.error is not None:
-            raise HandoffError("proof hand-off failed: %s" % self.error)
         self.exposed_s = _t.perf_counter() - t0
+        # A local transport error does NOT skip the status broadcast: the other ranks are (or will be) waiting in it.  Rank dst with
+        # a failed receiver broadcasts 0; a worker with a failed sender has told rank dst so (marker with ok = 0) and still listens.
         flag = torch.tensor([1], dtype=torch.int64)
         if self.rank == self.dst:
-            bad = [r for r, s in self._status.items() if not s] + ([self.dst] if not ok else [])
+            status = getattr(self, "_status", {})
+            bad = [r for r, s in status.items() if not s] + ([self.dst] if (not ok or self.error is not None) else [])
             missing = [u for u in range(self.n_units) if self.res[u] is None] if not bad else []
             flag[0] = 0 if (bad or missing) else 1
-        dist.broadcast(flag, src=self.dst, group=self.group)
+        try:
+            dist.broadcast(flag, src=self.dst, group=self.group)
+        except Exception as e:
+            raise HandoffError("proof hand-off failed: %s (status broadcast: %s)" % (self.error, e))
+        if self.error is not None:
+            raise HandoffError("proof hand-off failed: %s" % self.error)
         if int(flag[0]) != 1:
             raise HandoffError("the map stage failed on a rank: every rank gives the job up")
         return self.res if self.rank == self.dst else None

@@ -152,8 +152,9 @@ def from_json(text, cfg):
 #   OpeningSet { constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys, lookup_zs, lookup_zs_next }
 # and the reference's own wrappers (proof_gen::proof_types, what `serde_json::to_vec(&proof)` at /root/reference/leader/src/main.rs:60 writes):
 #   GeneratedTxnProof / GeneratedAggProof { p_vals: PublicValues, intern: ProofWithPublicInputs },  GeneratedBlockProof { b_height, intern }
-# The proof words also carry what upstream keeps in CommonCircuitData (degree_bits, wire / constant counts): kept under "common" so
-# that plonk_from_dict is an exact inverse.
+# The proof words also carry what upstream keeps in CommonCircuitData (degree_bits, wire / constant counts).  plonk_to_dict returns them
+# under "common" beside the upstream-shaped dict; the JSON of the reference's wrappers below has upstream's keys ONLY (no "common":
+# ADVICE r3) -- reading it back derives the four numbers from the proof itself (`common_of`: opening counts, Merkle path length).
 PLONK_MAGIC = 0x314B4C504C474B5A
 
 
@@ -224,21 +225,41 @@ def plonk_from_dict(d):
     return np.array(w, dtype=np.uint64), np.array(pw["public_inputs"], dtype=np.uint64)
 
 
+def common_of(proof_with_pis, cfg=None):
+    """CommonCircuitData's four numbers from a ProofWithPublicInputs-shaped dict: opening counts give the wire / routed / constant
+    counts, the length of a query's initial Merkle paths gives degree_bits.  cfg: the recursion config (default: the standard one)."""
+    if cfg is None:
+        from ._abi import standard_recursion_config
+        cfg = standard_recursion_config()
+    o = proof_with_pis["proof"]["openings"]
+    q0 = proof_with_pis["proof"]["opening_proof"]["query_round_proofs"][0]
+    npath = len(q0["initial_trees_proof"]["evals_proofs"][0][1]["siblings"])
+    return {"degree_bits": npath + cfg.cap_height - cfg.rate_bits, "num_wires": len(o["wires"]), "num_routed_wires": len(o["plonk_sigmas"]),
+            "num_constants": len(o["constants"])}
+
+
 def block_proof_to_json(block, cfg, public_inputs):
-    """GeneratedBlockProof { b_height, intern } as the leader prints it (/root/reference/leader/src/main.rs:60)"""
+    """GeneratedBlockProof { b_height, intern } as the leader prints it (/root/reference/leader/src/main.rs:60): upstream's two keys"""
     d = plonk_to_dict(block.intern, cfg, public_inputs)
-    return json.dumps({"b_height": int(block.b_height), "intern": d["proof_with_pis"], "common": d["common"]}, separators=(",", ":"))
+    return json.dumps({"b_height": int(block.b_height), "intern": d["proof_with_pis"]}, separators=(",", ":"))
 
 
-def block_proof_from_json(text):
+def block_proof_from_json(text, cfg=None):
     """-> (b_height, proof words, public inputs)"""
     j = json.loads(text)
-    words, pis = plonk_from_dict({"common": j["common"], "proof_with_pis": j["intern"]})
+    words, pis = plonk_from_dict({"common": common_of(j["intern"], cfg), "proof_with_pis": j["intern"]})
     return int(j["b_height"]), words, pis
 
 
 def txn_proof_to_json(agg_proof, cfg, public_inputs):
     """GeneratedTxnProof / GeneratedAggProof { p_vals, intern }: p_vals here = the tables' public inputs the unit carried"""
     d = plonk_to_dict(agg_proof.proof, cfg, public_inputs)
-    return json.dumps({"p_vals": [[int(x) for x in pv] for pv in agg_proof.public_values], "intern": d["proof_with_pis"], "common": d["common"]},
+    return json.dumps({"p_vals": [[int(x) for x in pv] for pv in agg_proof.public_values], "intern": d["proof_with_pis"]},
                       separators=(",", ":"))
+
+
+def txn_proof_from_json(text, cfg=None):
+    """-> (p_vals, proof words, public inputs)"""
+    j = json.loads(text)
+    words, pis = plonk_from_dict({"common": common_of(j["intern"], cfg), "proof_with_pis": j["intern"]})
+    return j["p_vals"], words, pis

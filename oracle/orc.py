@@ -409,11 +409,12 @@ def _prove_bound(rcfg, circ, wires, pubs):
     return p
 
 
-def prove_root(cfg, rcfg, items, rec):
+def prove_root(cfg, rcfg, items, rec, steps=None):
     """The oracle's restatement of prove_root: STARK proofs of all tables (orc.prove), then per table the initial wrapper and the
     shrinking wrappers, then the root proof.  `rec` supplies DATA only -- which circuits exist (rec.shrink_chain) and each circuit with
     its witness (rec.circuit) -- the flow and the binding rule (public inputs = table index, size and Poseidon digests of the child
-    proofs' words) are restated here.  Returns (root proof, all_proof, [shrunk proofs])."""
+    proofs' words) are restated here.  Returns (root proof, all_proof, [shrunk proofs]); `steps` (a list) receives every proof of every
+    chain as (table, step, degree_bits, proof)."""
     rc, all_proof = prove(cfg, items)
     assert rc == 0
     shrunk, at = [], 2
@@ -425,9 +426,13 @@ def prove_root(cfg, rcfg, items, rec):
         kind, key, bits = chain[0]
         circ, wires = rec.circuit(kind, key, bits)
         proof = _prove_bound(rcfg, circ, wires, np.concatenate([np.array([ti, it[1]], dtype=np.uint64), words_digest(words)]))
-        for kind, key, bits in chain[1:]:
+        if steps is not None:
+            steps.append((ti, 0, bits, proof))
+        for si, (kind, key, bits) in enumerate(chain[1:], 1):
             circ, wires = rec.circuit(kind, key, bits)
             proof = _prove_bound(rcfg, circ, wires, words_digest(proof))
+            if steps is not None:
+                steps.append((ti, si, bits, proof))
         shrunk.append(proof)
     assert at == all_proof.size
     circ, wires = rec.circuit("root")

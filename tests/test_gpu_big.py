@@ -56,3 +56,65 @@ def test_seven_table_unit_hashes_to_the_oracles_digest(ctx, ent):
         for d in ds:
             ctx.dev_free(d)
     assert proof.size == ent["words"] and _sha(proof) == ent["sha256"]
+
+
+# ---- the Plonk half at its real sizes (round 4): BASELINE configs[3] end to end
+@pytest.mark.parametrize("ent", GOLD.get("plonk_proofs", []), ids=lambda e: "plonk_2p%d" % e["degree_bits"])
+def test_recursion_shaped_plonk_proof_hashes_to_the_oracles_digest(ctx, ent):
+    """Recursion-shaped circuits (gates.py's gate set, 135 wires, standard_recursion_config) at the sizes of a real transaction's shrink
+    chains and root: 2^14, 2^15, 2^16 rows -- 8n-coset transforms of 2^17 .. 2^19 points, the `_split` combine up to 2^16 coefficients
+    and past it.  The oracle's proofs were computed once (tools/gen_golden_big.py --plonk 14,15,16); the GPU's words must hash alike."""
+    from eth_tx_proof_amd import plonk
+    from eth_tx_proof_amd._abi import standard_recursion_config
+    rcfg = standard_recursion_config()
+    circ, wires = plonk.recursion_circuit(degree_bits=ent["degree_bits"], seed=ent["seed"])
+    pub = np.array(ent["public_inputs"], dtype=np.uint64)
+    w = plonk.bind_public_inputs(circ, wires, plonk.SyntheticRecursion.public_inputs_hash(ctx, pub))
+    st = zl.PlonkState(ctx, rcfg, circ)
+    try:
+        assert [int(x) for x in st.digest()] == ent["circuit_digest"]
+        proof = zl.prove_plonk(st, w, pub)
+        assert proof.size == ent["words"]
+        assert _sha(proof) == ent["sha256"], "GPU Plonk proof of 2^%d rows differs from the oracle's (committed digest)" % ent["degree_bits"]
+        other = zl.Context(0)                      # a worker's context proves with the same prover data
+        try:
+            assert _sha(zl.prove_plonk(st, w, pub, ctx=other)) == ent["sha256"]
+        finally:
+            other.close()
+    finally:
+        st.free()
+
+
+@pytest.mark.parametrize("overlap", [False, True], ids=["upstream_order", "chains_overlapped"])
+@pytest.mark.parametrize("ent", GOLD.get("prove_root", []), ids=lambda e: "cfg4")
+def test_whole_prove_root_of_configs3_hashes_to_the_oracles_digests(ent, overlap):
+    """TxProof.execute at BASELINE configs[3]'s REAL sizes: seven tables (2^9 .. 2^17 rows), shrink chains [[14,12],[12],[13],[16,12],
+    [14,12],[14,12],[13]] and the 2^15 root over plonk.SyntheticRecursion() at size_shift 0 -- the transaction bench.py --workload
+    prove_root times.  Every proof of every chain, the AllProof and the root proof hash to the ORACLE's digests
+    (orc.prove_root, tools/gen_golden_big.py --root), in upstream's order in time and with the chains overlapped."""
+    from eth_tx_proof_amd import ops, plonk
+    old = ops.P_STATE
+    ops.P_STATE = None
+    try:
+        rec = plonk.SyntheticRecursion()
+        st = ops.set_prover_state_from_config(0, recursion=rec, chain_overlap=overlap)
+        tabs = []
+        for t, (w, lg) in enumerate(zip(ent["widths"], ent["log_sizes"])):
+            d, pub = zl.synth_trace_dev(st.ctx(), w, lg, ent["seed_base"] + 1000 * t)
+            tabs.append(ops.TableInput(air.cpu_like_air(w, min(19, w // 4)), lg, d, pub))
+        assert [[b for _, _, b in rec.shrink_chain(t, tb.air, tb.log_n)] for t, tb in enumerate(tabs)] == ent["chains"]
+        tm = {"collect": []}
+        root, _, all_proof = ops.prove_root(ops.GenerationInputs(tabs), tm)
+        assert all_proof.size == ent["all_proof"]["words"] and _sha(all_proof) == ent["all_proof"]["sha256"]
+        got = {(ti, si): p for ti, si, p in tm["collect"]}
+        assert len(got) == len(ent["chain_proofs"])
+        for e in ent["chain_proofs"]:
+            p = got[(e["table"], e["step"])]
+            assert p.size == e["words"] and _sha(p) == e["sha256"], "chain proof of table %d step %d (2^%d rows) differs from the oracle's" % (e["table"], e["step"], e["degree_bits"])
+        assert root.size == ent["root"]["words"] and _sha(root) == ent["root"]["sha256"], "root proof differs from the oracle's"
+        # TxProof.execute is this call
+        assert _sha(ops.TxProof().execute(ops.GenerationInputs(tabs)).proof) == ent["root"]["sha256"]
+    finally:
+        if ops.P_STATE is not None:
+            ops.P_STATE.drop_ctx()
+        ops.P_STATE = old

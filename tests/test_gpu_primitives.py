@@ -360,3 +360,35 @@ def test_packed_trace_upload_widens_to_the_u64_layout(ctx):
         want = c.astype(np.uint64)
         want = np.where(want >= P, want - P, want)
         assert (got[j] == want).all(), j
+
+
+def test_packed_upload_from_pinned_memory_then_a_proof_straight_away(zk, orc):
+    """zk_trace_upload_packed returns before its copies have run (pinned source).  The column offset table used to sit in the
+    per-proof staging buffer, which the next zk_prove_tables on the context resets and overwrites: on a FRESH context the table is at
+    staging offset 0, right where the proof's header words go.  Here: fresh context, pinned packed source, no synchronize, prove at
+    once through the C ABI -- the proof must be the oracle's proof of the widened trace."""
+    import ctypes as C
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import air
+    L = zk.lib()
+    log_n, n_cols = 10, 9
+    tr, pub = orc.synth_trace(n_cols, log_n, 5)
+    cfg = E.standard_fast_config()
+    prog = air.cpu_like_air(n_cols, 2)
+    rc, ref = orc.prove(cfg, [(prog, log_n, tr, pub)])
+    assert rc == 0
+    for _ in range(3):
+        c = zk.Context(0)
+        try:
+            src = zk.pinned_empty(c, tr.shape)
+            src[...] = tr
+            widths = np.full(n_cols, 8, dtype=np.uint8)
+            p = C.c_void_p()
+            c._chk(L.zk_trace_upload_packed(c.h, src.ctypes.data_as(C.c_void_p), C.c_uint32(log_n), C.c_uint32(n_cols),
+                                            widths.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(p)), "zk_trace_upload_packed")
+            proof = zk.prove_tables(c, cfg, [(prog, log_n, p.value, pub)])          # no synchronize in between
+            assert proof.size == ref.size and (proof == ref).all()
+            c.dev_free(p.value)
+            del src
+        finally:
+            c.close()

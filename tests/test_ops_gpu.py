@@ -168,11 +168,11 @@ def test_wire_formats_on_gpu_made_proofs(orc):
         txn = ops.AggregatableProof("Txn", root, pv)
         j = json.loads(wire.txn_proof_to_json(txn, rec.cfg, root_pubs))
         assert len(j["p_vals"]) == 2 and j["intern"]["public_inputs"] == [int(x) for x in root_pubs]
-        words, pis = wire.plonk_from_dict({"common": j["common"], "proof_with_pis": j["intern"]})
+        words, pis = wire.plonk_from_dict({"common": wire.common_of(j["intern"], rec.cfg), "proof_with_pis": j["intern"]})
         root_state = orc._plonk_state_for(rec.cfg, rec.circuit("root")[0])
         assert (words == root).all() and orc.verify_plonk(root_state, pis, words) == 0
         j["intern"]["proof"]["openings"]["plonk_zs"][0][0] ^= 1
-        assert orc.verify_plonk(root_state, pis, wire.plonk_from_dict({"common": j["common"], "proof_with_pis": j["intern"]})[0]) != 0
+        assert orc.verify_plonk(root_state, pis, wire.plonk_from_dict({"common": wire.common_of(j["intern"], rec.cfg), "proof_with_pis": j["intern"]})[0]) != 0
         # ---- the block proof
         block = leader.ProverInput(units).prove(leader.Runtime(num_workers=2))
         ref, blk_pubs, _ = orc.prove_block(st.config, rec.cfg, unit_items, rec)

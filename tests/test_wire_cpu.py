@@ -74,6 +74,12 @@ def test_plonk_wire_round_trip(orc):
     blk = ops.GeneratedBlockProof(7, proof)
     h, words, pis2 = wire.block_proof_from_json(wire.block_proof_to_json(blk, cfg, pubs))
     assert h == 7 and (words == proof).all() and (pis2 == pubs).all()
+    # upstream's keys only: GeneratedBlockProof { b_height, intern }, GeneratedTxnProof { p_vals, intern }
+    assert sorted(json.loads(wire.block_proof_to_json(blk, cfg, pubs))) == ["b_height", "intern"]
+    txt = wire.txn_proof_to_json(ops.AggregatableProof("Txn", proof, [pubs]), cfg, pubs)
+    assert sorted(json.loads(txt)) == ["intern", "p_vals"]
+    pv, words, pis2 = wire.txn_proof_from_json(txt, cfg)
+    assert (words == proof).all() and (pis2 == pubs).all() and pv == [[int(x) for x in pubs]]
     d["proof_with_pis"]["proof"]["openings"]["wires"][5][1] ^= 1
     assert orc.verify_plonk(st, pubs, wire.plonk_from_dict(d)[0]) != 0
     d["proof_with_pis"]["proof"]["openings"]["wires"][5][1] ^= 1
