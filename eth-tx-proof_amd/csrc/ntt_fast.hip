@@ -81,7 +81,24 @@ bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, con
         else if (need_load) { p.load_tab = pass_table(ctx, p, dit, false); p.tab_sub = 0; if (!p.load_tab) return false; }
     } else if (need_load && tab_on) p.load_tab = pass_table(ctx, p, dit, false);
     if (need_store && tab_on) p.store_tab = pass_table(ctx, p, dit, true);
+    // the kernel takes its per-position factors from ONE coalesced table per side or not at all: a pass whose table is not available
+    // (k > 24: 128 MiB and more per table; ZK_NTT_TAB switched off) and a permuting pass with an output scale go to the LDS radix-2 kernel
+    if ((need_load && !p.load_tab) || (need_store && !p.store_tab)) return false;
+    if (p.permute_out && (p.postA || p.post_const)) return false;
     size_t rows_per_col = ((size_t)1 << p.k) >> p.W;
+    {
+        // the kernel's addressing (ntt_fast_kernel.cuh): a tile is either inside one column (TILE passes; ROW passes with at least T rows
+        // per column) or holds T whole one-row columns (k == W); the per-thread part of an address is a 32-bit byte offset
+        const size_t T = (size_t)1 << p.TL;
+        if (row && rows_per_col != 1 && rows_per_col < T) return false;
+        if (p.k > 28) return false;
+        if (row && rows_per_col == 1) {
+            const size_t st = p.in_stride > p.out_stride ? p.in_stride : p.out_stride;
+            size_t sub = p.in_sub > p.out_sub ? p.in_sub : p.out_sub;
+            if (p.tab_sub > sub) sub = p.tab_sub;
+            if (((T * st + (((size_t)1 << p.cs_bits) - 1) * sub + ((size_t)1 << p.W)) >> 29) != 0) return false;
+        }
+    }
     bool cf_on = row ? (use_colfast & 1) : (use_colfast & 2);
     p.col_fast = cf_on ? (row ? (rows_per_col >= ((size_t)1 << p.TL) ? 1 : 0) : 1) : 0;
     if (!row && p.col_fast) {

@@ -17,10 +17,70 @@
 
 #include "ntt_radix.cuh"
 
+// Global addressing (round 4).  For every register mapping the pair (t, slot) of register q is the pair of register 0 -- a function of
+// the thread id only -- PLUS a pair that depends on q alone (NttGeom, compile-time): the thread bits and the register bits occupy
+// disjoint bit fields in all three mappings.  The element offset of an access is therefore
+//     [wave-uniform: column base + tile base + the register's part]  +  [per thread: ONE 32-bit byte offset per mapping and side],
+// which is the addressing mode of the hardware (global_load  vdst, voffset32, sbase64): the uniform part lives in scalar registers /
+// immediates and costs no vector instruction, the thread part is one VGPR instead of a hoisted 64-bit address per register.  Before,
+// hipcc formed 16 + 16 + 16 full addresses (v_lshl_add_u64 each) per thread and, bounded to 128 VGPRs, spilled up to 64 of them to
+// scratch in every one of the 47 instantiations; now no instantiation uses scratch (tools/kernel_resources.py, tests/test_abi_cpu.py).
+// Two shapes of tile: (A) all rows of the tile in one column (every TILE pass; ROW passes with at least T rows per column) and
+// (B) one row per column (ROW passes of whole transforms, k = W <= 12: the tile holds T columns).  The launcher routes anything else
+// to the LDS radix-2 kernel.
+template <bool ROW, int W> struct NttGeom {
+    static constexpr int P2 = (W - 4) < 4 ? (W - 4) : 4, P3 = W - 4 - P2, TL = 13 - W, R = 1 << (W - 4);
+    // the part of (t, slot) of mapping m (0 = H, 1 = M, 2 = L) that register q contributes; map_X(q) = map_X(0) + these
+    static constexpr u32 t_uni(int m, int q) {
+        if (!ROW || m == 0) return 0;
+        return m == 1 ? (u32)(q >> P2) << (5 - P3) : (u32)(q >> P3) << (5 - P2);
+    }
+    static constexpr u32 slot_uni(int m, int q) {
+        if (m == 0) return (u32)q * R;
+        if (m == 1) { const u32 g = q >> P2, i = q & ((1 << P2) - 1); return ROW ? (i << P3) : (((g << P2) << (P2 + P3)) + (i << P3)); }
+        const u32 g = q >> P3, i = q & ((1 << P3) - 1);
+        return ROW ? i : ((g << (W - 4 + P3)) + i);
+    }
+};
+// 2^e mod p for the exact twin's in-network twiddles: 2^64 = 2^32 - 1, 2^96 = -1, 2^192 = 1
+__host__ __device__ constexpr u64 ntt_pow2(int e) {
+    e %= 192;
+    if (e >= 96) { const u64 r = ntt_pow2(e - 96); return 0xFFFFFFFF00000001ull - r; }
+    return e < 64 ? (1ull << e) : (((1ull << 32) - 1) << (e - 64));
+}
+static_assert(ntt_pow2(0) == 1 && ntt_pow2(72) == (1ull << 40) - 256 && ntt_pow2(96) == 0xFFFFFFFF00000000ull && ntt_pow2(191) == 0xFFFFFFFF00000001ull - (0xFFFFFFFFull << 31), "2^e mod p");
+// x[sbase + thread byte offset]: sbase wave-uniform (scalar registers), the offset one 32-bit VGPR
+// (readfirstlane makes the base one opaque scalar value: left visible, hipcc re-associates  base + (uniform + thread)  into a 64-bit
+// vector sum and is back to one v_lshl_add_u64 and two VGPRs per access; an empty asm with an "s" operand does the same for loads OR
+// stores but, used for both, ends in "illegal VGPR to SGPR copy".  The access is typed as GLOBAL memory: behind the intrinsic the
+// pointer's address space is no longer inferred and the access would become flat_load / flat_store.)
+__device__ __forceinline__ u64 ntt_uniform(u64 v) {
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
+// NTT_FLOOR (tools/ntt_floor.hip only; never defined for the library): 1 = the pass without its global data traffic -- a load is a value
+// made from its address, a store happens only for a value that never occurs -- 2 = without the LDS exchanges between phases as well:
+// what is left is the instruction stream of the butterflies, twiddles and factor products, whose run time is the MEASURED issue-bound floor.
+#ifndef NTT_FLOOR
+#define NTT_FLOOR 0
+#endif
+__device__ __forceinline__ u64 ntt_ld(const u64 *sbase, u32 thr_bytes) {
+    const u64 b = ntt_uniform((u64)sbase);
+#if NTT_FLOOR
+    return (b + thr_bytes) | 1;
+#else
+    return *(const __attribute__((address_space(1))) u64 *)(b + thr_bytes);
+#endif
+}
+__device__ __forceinline__ void ntt_st(u64 *sbase, u32 thr_bytes, u64 v) {
+    const u64 b = ntt_uniform((u64)sbase);
+#if NTT_FLOOR
+    if (v != 0x5A5A5A5A5A5A5A5Aull) return;
+#endif
+    *(__attribute__((address_space(1))) u64 *)(b + thr_bytes) = v;
+}
+
 template <bool DIT, bool ROW, int W, bool INV, bool CS = false>
-// Two 512-thread workgroups per CU (64-78 KiB of LDS each) need <= 128 VGPRs: with the tile shape a constant hipcc hoists every
-// address of the pass and asks for ~140; bounded to 128 it spills 10-28 of them to scratch and is still the fastest variant measured
-// (from_values NTT at 2^20 x 93: 2.95 ms; unbounded 140 VGPRs: 3.98 ms; run-time tile shape, 84 VGPRs, +25 instructions: 3.3 ms).
+// Two 512-thread workgroups per CU (64-78 KiB of LDS each) need <= 128 VGPRs.
 // CS (coset-merged LDE): the launch covers n_cols << cs_bits VIRTUAL columns; virtual column v = (real column v >> cs_bits, coset slot
 // v & mask): its data sits at column * stride + slot * sub on either side, and its input factors at load_tab + slot * tab_sub.
 __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
@@ -99,55 +159,74 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
     };
     // mapping ids: 0 = H, 1 = M, 2 = L
     auto map_any = [&](int m, int q, u32 &t, u32 &slot) { if (m == 0) map_H(q, t, slot); else if (m == 1) map_M(q, t, slot); else map_L(q, t, slot); };
-    // global position of (t, slot); returns false when the row is past the end (ROW tail block).  Positions and row numbers fit
-    // 32 bits (k <= 30 and the launcher bounds rows * columns), so only the final address is formed in 64 bits.
-    const u32 base32 = (u32)base, row032 = (u32)row0, rpc_mask = (u32)rows_per_col - 1u, kW = (u32)(p.k - W), total32 = (u32)total_rows;
-    auto gpos = [&](u32 t, u32 slot, size_t &c, u32 &pos) -> bool {
-        if (ROW) {
-            u32 rid = row032 + t;
-            if (rid >= total32) return false;
-            c = rid >> kW; pos = ((rid & rpc_mask) << W) + slot;      // rows_per_col = 2^(k-W)
-        } else { c = col; pos = base32 + (slot << S) + t; }
-        return true;
+    // ---- global addressing (see the top of the file): per side a uniform element base and one per-thread byte offset per mapping
+    using GM = NttGeom<ROW, W>;
+    const u32 base32 = (u32)base, row032 = (u32)row0, rpc_mask = (u32)rows_per_col - 1u, total32 = (u32)total_rows;
+    const u32 cs_bits = CS ? (u32)p.cs_bits : 0u, cs_mask = CS ? ((1u << cs_bits) - 1u) : 0u;
+    const bool modeB = ROW && rows_per_col == 1;                       // one row per column: the tile's rows are T different columns
+    // offset of (virtual) column v on a side with column stride `stride` and coset-slot stride `sub`
+    auto col_off = [&](size_t v, size_t stride, size_t sub) -> size_t { return CS ? (v >> cs_bits) * stride + (v & cs_mask) * sub : v * stride; };
+    const size_t vcolA = ROW ? (size_t)(row032 >> (u32)(p.k - W)) : col;                  // shape A: the tile's column
+    const u32 rr0 = row032 & rpc_mask;                                                   // shape A, ROW: first row of the tile inside its column
+    // uniform element offset of register q's access in mapping m: side = 0 input, 1 output, 2 load table, 3 store table
+    auto uni_pos = [&](int m, int q) -> u32 {                                            // position inside the column (shape A)
+        return ROW ? ((rr0 + GM::t_uni(m, q)) << W) + GM::slot_uni(m, q) : base32 + (GM::slot_uni(m, q) << S);
     };
-
-    // element offset of (virtual) column c on the input / output side, and of its slice of the load table
-    const u32 cs_mask = CS ? ((1u << p.cs_bits) - 1u) : 0u;
-    auto in_off = [&](size_t c) -> size_t { return CS ? (c >> p.cs_bits) * p.in_stride + (c & cs_mask) * p.in_sub : c * p.in_stride; };
-    auto out_off = [&](size_t c) -> size_t { return CS ? (c >> p.cs_bits) * p.out_stride + (c & cs_mask) * p.out_sub : c * p.out_stride; };
-    auto tab_off = [&](size_t c) -> size_t { return CS ? (c & cs_mask) * p.tab_sub : 0; };
+    auto uni_off = [&](int side, int m, int q) -> size_t {
+        const size_t stride = side == 0 ? p.in_stride : side == 1 ? p.out_stride : 0, sub = side == 0 ? p.in_sub : side == 1 ? p.out_sub : (side == 2 ? p.tab_sub : 0);
+        if (modeB) return col_off((size_t)row032 + GM::t_uni(m, q), stride, sub) + GM::slot_uni(m, q);
+        return (side == 3 ? 0 : col_off(vcolA, stride, sub)) + uni_pos(m, q);
+    };
+    // per-thread byte offset of mapping m on a side (the launcher has checked that it fits 32 bits)
+    auto thr_pos = [&](int m) -> u32 {                                                   // position part (shape A), in elements
+        u32 t, slot; map_any(m, 0, t, slot);
+        return ROW ? (t << W) + slot : (slot << S) + t;
+    };
+    auto thr_off = [&](int side, int m) -> u32 {
+        u32 t, slot; map_any(m, 0, t, slot);
+        if (modeB) {
+            const size_t stride = side == 0 ? p.in_stride : side == 1 ? p.out_stride : 0, sub = side == 0 ? p.in_sub : side == 1 ? p.out_sub : (side == 2 ? p.tab_sub : 0);
+            return (u32)(col_off(t, stride, sub) + slot) << 3;
+        }
+        return thr_pos(m) << 3;
+    };
+    // shape B only: rows past the last column are skipped (t of register q = thread part + GM::t_uni); shape A tiles are always whole
+    auto row_lim = [&](int m) -> int { u32 t, slot; map_any(m, 0, t, slot); return modeB ? (int)(total32 - row032) - (int)t : 0x7fffffff; };
 
     u64 x[16];
     constexpr int FIRST_DIT = P3 > 0 ? 2 : (P2 > 0 ? 1 : 0);     // first phase mapping of DIT == last phase mapping of DIF
-    const int load_map = DIT ? (ROW ? 0 : FIRST_DIT) : 0;
+    constexpr int load_map = DIT ? (ROW ? 0 : FIRST_DIT) : 0;
+    const u32 ld_thr = thr_off(0, load_map), ldtab_thr = thr_off(2, load_map);
+    const int ld_lim = row_lim(load_map);
 
     // everything from the global loads to the last butterfly, for either arithmetic (glx<false> fast / glx<true> exact)
     auto to_lds = [&](int m) {
-        if (act) {
+        if (act && NTT_FLOOR < 2) {
 #pragma unroll
             for (int q = 0; q < 16; q++) { u32 t, slot; map_any(m, q, t, slot); sh[lds_idx(t, slot)] = x[q]; }
         }
     };
     auto from_lds = [&](int m) {
-        if (act) {
+        if (act && NTT_FLOOR < 2) {
 #pragma unroll
             for (int q = 0; q < 16; q++) { u32 t, slot; map_any(m, q, t, slot); x[q] = sh[lds_idx(t, slot)]; }
         }
     };
 
     auto compute = [&](auto &fx) {
-    // the in-network twiddles as table values: only the exact arithmetic reads them (the fast arithmetic shifts), so they are
-    // loaded here rather than held in 16 registers through the fast path
+    // the in-network twiddles as values: only the exact arithmetic multiplies by them (the fast arithmetic shifts).  They are powers of
+    // w_16 = 2^12, i.e. compile-time constants (ntt_pow2) -- literals at their uses instead of eight table loads and 16 live registers
     u64 tw16[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) tw16[j] = std::remove_reference_t<decltype(fx)>::exact ? RW[j << (W - 4)] : 0;
+    for (int j = 0; j < 8; j++) tw16[j] = std::remove_reference_t<decltype(fx)>::exact ? ntt_pow2(INV ? (j ? 96 - 12 * j : 0) : 12 * j) : 0;
     // ---------------------------------------------------------------- load (+ input scale, + DIT pass pre-twiddle)
     // Loads (and the factor loads) are guarded per lane and issued back to back; the products run after them in wave-uniform
     // control flow, because the sticky word of glx<false> is a scalar: inactive lanes multiply 0 by 1.
     {
-        // which factor an element gets is a property of the PASS: decided once here, so that the unrolled per-element code below
-        // carries no run-time branch (mode 0: none, 1: one coalesced table read, 2: the two-level tables)
-        const bool need_mul = p.load_tab || p.preA || (DIT && S > 0);
+        // every per-position factor of a pass (input scale, coset shift, inter-pass twiddle) comes folded into ONE coalesced table
+        // (p.load_tab, built once per shape by the launcher); a pass whose factors would have to be formed from the two-level tables
+        // at run time (k > 24) is not taken by this kernel.  Decided once here: the unrolled code below carries no run-time branch.
+        const bool need_mul = p.load_tab != nullptr;
         u64 f[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) { x[q] = 0; f[q] = 1; }
@@ -155,32 +234,17 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
             if (!act) return;
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                u32 t, slot; map_any(load_map, q, t, slot);
-                size_t c; u32 pos;
-                if (gpos(t, slot, c, pos)) {
-                    u64 v = p.in[in_off(c) + pos];
+                if (ld_lim > (int)GM::t_uni(load_map, q)) {
+                    u64 v = ntt_ld(p.in + uni_off(0, load_map, q), ld_thr);
                     if (decltype(CANON)::value) v = gl_canon(v);
                     x[q] = v;
-                    if (decltype(MODE)::value == 1) f[q] = p.load_tab[tab_off(c) + pos];
-                    else if (decltype(MODE)::value == 2) {
-                        u64 g1 = 1;
-                        if (p.preA) { u32 j = p.pre_bitrev ? bitrev_u32(pos, p.k) : pos; g1 = tab2(p.preA, p.preB, j); }
-                        if (DIT && S > 0) {
-                            u32 inner = pos & ((1u << S) - 1);
-                            u64 g2 = tab2(p.twA, p.twB, bitrev_u32(slot, W) * inner);
-                            g1 = p.preA ? gl_mul(g1, g2) : g2;
-                        }
-                        f[q] = g1;
-                    }
+                    if (decltype(MODE)::value == 1) f[q] = ntt_ld(p.load_tab + uni_off(2, load_map, q), ldtab_thr);
                 }
             }
         };
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-        if (p.canon_in) {
-            if (p.load_tab) load_all(I1{}, std::true_type{}); else if (need_mul) load_all(I2{}, std::true_type{}); else load_all(I0{}, std::true_type{});
-        } else {
-            if (p.load_tab) load_all(I1{}, std::false_type{}); else if (need_mul) load_all(I2{}, std::false_type{}); else load_all(I0{}, std::false_type{});
-        }
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        if (p.canon_in) { if (need_mul) load_all(I1{}, std::true_type{}); else load_all(I0{}, std::true_type{}); }
+        else { if (need_mul) load_all(I1{}, std::false_type{}); else load_all(I0{}, std::false_type{}); }
         if (wact && need_mul) {
 #pragma unroll
             for (int q = 0; q < 16; q++) x[q] = fx.mulw(x[q], f[q]);
@@ -273,7 +337,7 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
 
     // ---------------------------------------------------------------- store
     constexpr int LAST_DIF = FIRST_DIT;
-    int smap = DIT ? 0 : LAST_DIF;
+    constexpr int SMAP = (DIT || ROW) ? 0 : LAST_DIF;                  // mapping of the plain store (DIF ROW tiles exchange into mapping 0 first)
     if (DIT && p.permute_out) {
         // scatter whole rows to bit-reversed positions: go through LDS so that lanes walk consecutive output positions
         // Exchange layout for the TILE case: element (t, slot) sits at t*2^W + swz(bitrev(slot)), so the read side
@@ -293,65 +357,48 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
             }
         } else to_lds(0);
         __syncthreads();
-        auto scatter = [&](auto POST) {
-            if (!act) return;
+        // output element lin = tid + 512 q of the tile: row t = lin >> W, position pe = lin & (2^W - 1) inside the row; the thread bits
+        // (tid < 512) and the register bits (512 q) are disjoint, and so are their images under the bit reversals below, so the global
+        // offset is again a per-thread part (sc_thr) plus a uniform part per register
+        const u32 t_thr = tid >> W, pe_thr = tid & ((1u << W) - 1), inner0 = base32 & ((1u << S) - 1);
+        u32 sc_thr; int sc_lim = 0x7fffffff;
+        if (ROW) {
+            if (modeB) { sc_thr = (u32)(col_off(t_thr, p.out_stride, p.out_sub) + pe_thr) << 3; sc_lim = (int)(total32 - row032) - (int)t_thr; }
+            else sc_thr = ((t_thr << W) + pe_thr) << 3;
+        } else sc_thr = ((bitrev_u32(t_thr, S) << W) + pe_thr) << 3;
+        if (act) {                 // (a permuting pass with an output scale is not taken by this kernel: the launcher checks)
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                u32 lin = tid + nact * q;
-                u32 t = lin >> W, pe = lin & ((1u << W) - 1), e = bitrev_u32(pe, W);
-                u64 v = pswz ? sh[pidx(t, pe)] : sh[lds_idx(t, e)];
-                size_t c; u32 pos, K;
-                if (ROW) {
-                    u32 rid = row032 + t;
-                    if (rid >= total32) continue;
-                    c = rid >> kW; pos = ((rid & rpc_mask) << W) + pe; K = ((rid & rpc_mask) << W) + e;
-                } else {
-                    c = col;
-                    u32 inner = (base32 & ((1u << S) - 1)) + t;
-                    pos = (bitrev_u32(inner, S) << W) + pe; K = (e << S) + inner;
-                }
-                if (decltype(POST)::value) {
-                    if (p.postA) v = gl_mul(v, tab2(p.postA, p.postB, K));      // exact products: the permuting pass rarely has an output scale
-                    if (p.post_const) v = gl_mul(v, p.post_const);
-                }
-                p.out[out_off(c) + pos] = v;
+                const u32 t_uni = (512u * (u32)q) >> W, pe_uni = (512u * (u32)q) & ((1u << W) - 1);
+                if (ROW && !(sc_lim > (int)t_uni)) continue;
+                const u32 t = t_thr + t_uni, pe = pe_thr + pe_uni, e = bitrev_u32(pe, W);
+                const u64 v = pswz ? sh[pidx(t, pe)] : sh[lds_idx(t, e)];
+                size_t ub;
+                if (ROW) ub = modeB ? col_off((size_t)row032 + t_uni, p.out_stride, p.out_sub) + pe_uni
+                                    : col_off(vcolA, p.out_stride, p.out_sub) + ((rr0 + t_uni) << W) + pe_uni;
+                else ub = col_off(vcolA, p.out_stride, p.out_sub) + ((bitrev_u32(inner0, S) + bitrev_u32(t_uni, S)) << W) + pe_uni;
+                ntt_st(p.out + ub, sc_thr, v);
             }
-        };
-        if (p.postA || p.post_const) scatter(std::true_type{}); else scatter(std::false_type{});
+        }
         return;
     }
-    if (!DIT && ROW && LAST_DIF != 0) { __syncthreads(); to_lds(LAST_DIF); __syncthreads(); from_lds(0); smap = 0; }
+    if (!DIT && ROW && LAST_DIF != 0) { __syncthreads(); to_lds(LAST_DIF); __syncthreads(); from_lds(0); }
     // same structure as the load side: guarded batched factor loads, products in wave-uniform control flow, guarded stores;
     // x[] is left intact, so a flagged wave runs the loop again with exact products and overwrites what it stored
+    const u32 st_thr = thr_off(1, SMAP), sttab_thr = thr_off(3, SMAP);
+    const int st_lim = row_lim(SMAP);
     auto store_plain = [&](auto &fx) {
-        const bool need_mul = p.store_tab || (!DIT && S > 0) || p.postA || p.post_const;
+        const bool need_mul = p.store_tab != nullptr;             // as on the load side: one table or nothing
         u64 f[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) f[q] = 1;
-        // as on the load side: the factor source is decided once per workgroup (mode 1: table, 2: two-level tables)
-        auto factors = [&](auto MODE) {
-            if (!act) return;
+        if (act && need_mul) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                u32 t, slot; map_any(smap, q, t, slot);
-                size_t c; u32 pos;
-                if (!gpos(t, slot, c, pos)) continue;
-                if (decltype(MODE)::value == 1) f[q] = p.store_tab[pos];
-                else {
-                    const u32 e = DIT ? slot : bitrev_u32(slot, W);
-                    u64 g1 = 1; bool have = false;
-                    if (!DIT && S > 0) { u32 inner = pos & ((1u << S) - 1); g1 = tab2(p.twA, p.twB, e * inner); have = true; }
-                    if (p.postA) {
-                        u32 K = ROW ? (((pos >> W) << W) + e) : (u32)(((base >> (W + S)) << (W + S)) + ((size_t)e << S) + (pos & ((1u << S) - 1)));
-                        u64 g2 = tab2(p.postA, p.postB, K);
-                        g1 = have ? gl_mul(g1, g2) : g2; have = true;
-                    }
-                    if (p.post_const) g1 = have ? gl_mul(g1, p.post_const) : p.post_const;
-                    f[q] = g1;
-                }
+                if (!(st_lim > (int)GM::t_uni(SMAP, q))) continue;
+                f[q] = ntt_ld(p.store_tab + uni_off(3, SMAP, q), sttab_thr);
             }
-        };
-        if (need_mul) { if (p.store_tab) factors(std::integral_constant<int, 1>{}); else factors(std::integral_constant<int, 2>{}); }
+        }
         if (wact && need_mul) {
 #pragma unroll
             for (int q = 0; q < 16; q++) f[q] = fx.mul(x[q], f[q]);            // f now holds the values to store
@@ -359,10 +406,8 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
         if (act) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
-                u32 t, slot; map_any(smap, q, t, slot);
-                size_t c; u32 pos;
-                if (!gpos(t, slot, c, pos)) continue;
-                p.out[out_off(c) + pos] = need_mul ? f[q] : x[q];
+                if (!(st_lim > (int)GM::t_uni(SMAP, q))) continue;
+                ntt_st(p.out + uni_off(1, SMAP, q), st_thr, need_mul ? f[q] : x[q]);
             }
         }
     };

@@ -6,9 +6,11 @@
 template <int Q> struct BR { __device__ static constexpr u32 rev(u32 i) { u32 r = 0; for (int b = 0; b < Q; b++) if (i & (1u << b)) r |= 1u << (Q - 1 - b); return r; } };
 
 // radix-2^Q network on registers x[g0 .. g0 + 2^Q); tw16[j] = w_16^j (j < 8) in the pass direction.
-// The twiddles inside a network are powers of w_16 = 2^12.  The exact arithmetic multiplies by the table value; the fast arithmetic
+// The twiddles inside a network are powers of w_16 = 2^12.  The exact arithmetic multiplies by the value tw16[e]; the fast arithmetic
 // shifts: forward w_16^e = 2^(12e); inverse w_16^-e = 2^(192 - 12e) = -2^(96 - 12e), the sign being absorbed by the butterfly that
 // follows (DIT) or precedes (DIF) the twiddle: u +- (-t v) swaps the two outputs, (u - v)(-t) = (v - u) t swaps the two inputs.
+// So tw16[e] = 2^(12e) forward and 2^(96 - 12e) inverse (the POSITIVE power; round 4: the exact twin takes the sign the same way,
+// which makes its twiddles the same small set of constants in both directions).
 template <int E16, bool INV, class G> __device__ __forceinline__ u64 tw_mul(G &g, u64 v, const u64 (&tw16)[8]) {
     if (G::exact) return g.mulw(v, tw16[E16]);
     return g.template mul_pow2<INV ? 96 - 12 * E16 : 12 * E16>(v);
@@ -18,7 +20,7 @@ __device__ __forceinline__ void radix_layer_step(G &g, u64 (&x)[16], const int g
     constexpr int h = DIT ? S : (Q - 1 - S);
     constexpr int i1 = ((B0 >> h) << (h + 1)) | (B0 & ((1 << h) - 1)), j1 = i1 + (1 << h);
     constexpr int e1 = ((i1 & ((1 << h) - 1)) << (Q - 1 - h)) << (4 - Q);            // twiddle as a power of w_16
-    constexpr bool neg = INV && !G::exact;                                           // fast inverse twiddles are -2^s
+    constexpr bool neg = INV;                // inverse twiddles are -2^s: both arithmetics multiply by 2^s and let the butterfly take the sign
     if (Q == 1) {
         u64 &u = x[g0 + i1], &v = x[g0 + j1];
         if (DIT) {

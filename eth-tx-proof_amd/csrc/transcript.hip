@@ -9,132 +9,116 @@
 #include "poseidon_wave.cuh"
 #include "transcript.h"
 
-// The kernel runs as ONE wave.  The challenger is staged in LDS; every lane executes the (uniform) control flow, lane 0
-// does the bookkeeping writes, and the permutation is the wave-wide one (poseidon_wave.cuh): state element l in lane l, the
-// whole wave working on the one permutation -- a sponge is a serial chain, so the latency of ONE permutation is all that counts.
-// (bit 2 of ZK_POSEIDON_MFMA selects the older 16-lane version, poseidon_coop.cuh, for comparison and for the tests.)
-// One copy of the permutation code in the kernel (every call site jumps here): the instruction stream of a permutation is what
-// the single wave waits for, so it should stay resident in the instruction cache.
-struct ChPerm {
-    const u64 *wtab; bool wave; u64 force_redo;
-    __device__ __noinline__ u64 run(u64 s, int lane) const {
-        if (wave) return psdw::permute(s, lane, wtab, force_redo);
-        return psdc::permute16(s, lane & 15, lane & ~15);
-    }
-};
-__device__ void ch_duplex(DevChallenger *c, ChPerm &P) {
-    const int lane = threadIdx.x, l = lane & 15;
-    u64 s = 0;
-    if (l < 12) s = c->state[l];
-    if ((u32)l < c->n_in) s = c->inbuf[l];
-    __syncthreads();
-    s = P.run(s, lane);
-    if (lane < 12) c->state[lane] = s;
-    if (lane < 8) c->outbuf[lane] = s;
-    if (lane == 0) { c->n_in = 0; c->n_out = 8; }
-    __syncthreads();
-}
-__device__ void ch_observe(DevChallenger *c, ChPerm &P, u64 x) {
-    if (threadIdx.x == 0) { c->n_out = 0; c->inbuf[c->n_in] = gl_canon(x); c->n_in = c->n_in + 1; }
-    __syncthreads();
-    if (c->n_in == 8) ch_duplex(c, P);
-}
-__device__ u64 ch_get(DevChallenger *c, ChPerm &P) {
-    if (c->n_in || !c->n_out) ch_duplex(c, P);
-    u64 v = c->outbuf[c->n_out - 1];
-    __syncthreads();
-    if (threadIdx.x == 0) c->n_out = c->n_out - 1;
-    __syncthreads();
-    return v;
+// The kernel runs as ONE wave and keeps the whole challenger in registers (round 4): state word l in lane l (l < 12), pending input l
+// in lane l (l < 8), the two counters wave-uniform.  Upstream's output buffer is the first eight state words as of the last permutation
+// -- between two permutations nothing writes the state (inputs wait in the input buffer: overwrite-mode duplex) -- so a challenge is a
+// v_readlane of the state, an observed value a v_writelane-like select into the input register, and nothing goes through LDS or a
+// barrier on the serial chain.  The permutation is the wave-wide one (poseidon_wave.cuh): the whole wave works on ONE permutation, its
+// latency is all that counts.  (bit 2 of ZK_POSEIDON_MFMA selects the older 16-lane version, poseidon_coop.cuh, for comparison and
+// for the tests.)
+// The op list runs as a state machine whose loop body has exactly ONE permutation site: every step is "things to do before a possible
+// duplexing -> duplexing if needed -> things to do after it".  Before, the permutation was a __noinline__ function with several call
+// sites, and a call costs a stack frame: 32 bytes of scratch per lane in a kernel that every stream of every proof launches hundreds
+// of times (VERDICT r3 / DESIGN.md section 9: no shipped kernel uses scratch).
+__device__ __forceinline__ u64 ch_rdlane(u64 v, int l) {           // l wave-uniform
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
 }
 
 __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpList ops, u64 *err, int wave, u64 force_redo) {
-    __shared__ DevChallenger L;
     __shared__ u64 wtab[psdw::TAB_WORDS];
-    DevChallenger *c = &L;
     const int lane = threadIdx.x;
-    ChPerm P; P.wave = wave != 0; P.wtab = wtab; P.force_redo = force_redo;
-    if (P.wave) psdw::fill<64>(wtab);
-    {
-        const u64 *src = (const u64 *)gc; u64 *dst = (u64 *)c;
-        for (u32 i = lane; i < sizeof(DevChallenger) / 8; i += 64) dst[i] = src[i];
-    }
+    if (wave) psdw::fill<64>(wtab);
+    u64 st = lane < 12 ? gc->state[lane] : 0;
+    u64 ib = lane < 8 ? gc->inbuf[lane] : 0;
+    u32 n_in = gc->n_in, n_out = gc->n_out;
     __syncthreads();
-    for (int k = 0; k < ops.n; k++) {
-        const TOp &o = ops.op[k];
+    int k = 0;
+    u32 i = 0;                      // progress inside op k
+    u64 pref = 0; u32 pref_at = ~0u;    // OBSERVE: src[pref_at + lane] for lane < 8, loaded one permutation ahead
+    while (k < ops.n) {
+        const TOp o = ops.op[k];
+        bool need = false;          // duplexing in this step
+        int post = 0;               // 1: pop a challenge -> dst[i - 1]   2: ... masked to aux bits   3: compact   4: PoW response
+        u64 w_pow = 0;
         switch (o.kind) {
         case TOP_INIT:
-            if (lane < 12) c->state[lane] = 0;
-            if (lane == 0) { c->n_in = 0; c->n_out = 0; }
-            __syncthreads();
-            break;
-        case TOP_OBSERVE: {
-            // element by element until the input buffer is empty, then whole rate-sized chunks with the sponge state kept in
-            // registers: one coalesced (prefetched) load and one permutation per 8 elements -- wide opening sets (thousands of
-            // columns) are a serial chain of permutations, so everything else must stay off that chain
-            u32 i = 0;
-            while (i < o.n && c->n_in != 0) ch_observe(c, P, o.src[i++]);
-            if (i + 8 <= o.n) {
-                const int l = lane & 15;
-                u64 st = l < 12 ? c->state[l] : 0;
-                u64 nxt = l < 8 ? gl_canon(o.src[i + l]) : 0;
-                while (i + 8 <= o.n) {
-                    const u64 cur = nxt;
-                    i += 8;
-                    if (i + 8 <= o.n && l < 8) nxt = gl_canon(o.src[i + l]);
-                    if (l < 8) st = cur;
-                    st = P.run(st, lane);
-                    if (l >= 12) st = 0;
-                }
-                __syncthreads();
-                if (lane < 12) c->state[lane] = st;
-                if (lane < 8) c->outbuf[lane] = st;
-                if (lane == 0) { c->n_in = 0; c->n_out = 8; }
-                __syncthreads();
+            st = 0; n_in = 0; n_out = 0; k++; i = 0;
+            continue;
+        case TOP_OBSERVE:
+        case TOP_OBSERVE_BASE_AS_EXT: {
+            const u32 total = o.kind == TOP_OBSERVE ? o.n : 2 * o.n;
+            if (i >= total) { k++; i = 0; pref_at = ~0u; continue; }
+            if (o.kind == TOP_OBSERVE && n_in == 0 && i + 8 <= total) {
+                // a whole rate-sized chunk: one coalesced load (issued before the previous permutation when the chunks follow each
+                // other), one permutation per 8 elements -- wide opening sets are a serial chain of permutations
+                u64 v = pref;
+                if (pref_at != i) v = lane < 8 ? o.src[i + lane] : 0;
+                ib = gl_canon(v);
+                n_in = 8; i += 8;
+                if (i + 8 <= total) { pref = lane < 8 ? o.src[i + lane] : 0; pref_at = i; }
+            } else {
+                const u64 x = o.kind == TOP_OBSERVE ? gl_canon(o.src[i]) : ((i & 1) ? 0 : gl_canon(o.src[i >> 1]));
+                if ((u32)lane == n_in) ib = x;
+                n_in++; i++;
             }
-            while (i < o.n) ch_observe(c, P, o.src[i++]);
+            n_out = 0;
+            need = n_in == 8;
             break;
         }
-        case TOP_OBSERVE_BASE_AS_EXT:
-            for (u32 i = 0; i < o.n; i++) { ch_observe(c, P, o.src[i]); ch_observe(c, P, 0); }
-            break;
         case TOP_GET:
-            for (u32 i = 0; i < o.n; i++) { u64 v = ch_get(c, P); if (lane == 0) o.dst[i] = v; }
+        case TOP_GET_INDICES:
+            if (i >= o.n) { k++; i = 0; continue; }
+            need = n_in != 0 || n_out == 0;
+            post = o.kind == TOP_GET ? 1 : 2; i++;
             break;
         case TOP_COMPACT:
-            if (c->n_in) ch_duplex(c, P);
-            if (lane == 0) c->n_out = 0;
-            __syncthreads();
-            if (o.dst && lane < 12) o.dst[lane] = c->state[lane];
+            need = n_in != 0; post = 3; k++; i = 0;
             break;
-        case TOP_POW_SETUP: {
+        case TOP_POW_SETUP:
             // fri_proof_of_work: duplex_intermediate_state = sponge state with pending inputs written in; dst[12] = witness position
-            if (lane < 12) o.dst[lane] = (u32)lane < c->n_in ? c->inbuf[lane] : c->state[lane];
-            if (lane == 0) { o.dst[12] = c->n_in; o.dst[13] = ~0ULL; }    // dst[13] = best witness so far
-            break;
-        }
-        case TOP_POW_FINISH: {
-            u64 w = __hip_atomic_load((u64 *)&o.src[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (w == ~0ULL) { if (lane == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW); w = 0; }
-            ch_observe(c, P, w);
-            u64 resp = ch_get(c, P);
-            if (lane == 0) {
-                if ((u32)__clzll((long long)resp) < o.n) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW);
-                o.dst[0] = w;
+            if (lane < 12) o.dst[lane] = (u32)lane < n_in ? ib : st;
+            if (lane == 0) { o.dst[12] = n_in; o.dst[13] = ~0ULL; }    // dst[13] = best witness so far
+            k++; i = 0;
+            continue;
+        case TOP_POW_FINISH:
+            if (i == 0) {           // observe the witness
+                u64 w = __hip_atomic_load((u64 *)&o.src[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (w == ~0ULL) { if (lane == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW); w = 0; }
+                if (lane == 0) o.dst[0] = w;
+                if ((u32)lane == n_in) ib = gl_canon(w);
+                n_in++; n_out = 0; need = n_in == 8; i = 1;
+            } else {                // the response
+                need = n_in != 0 || n_out == 0; post = 4; k++; i = 0;
             }
             break;
+        default:
+            k++; i = 0;
+            continue;
         }
-        case TOP_GET_INDICES:
-            // fri_prover_query_rounds: x_index = challenge.to_canonical_u64() as usize % lde_size (lde_size = 2^o.aux)
-            for (u32 i = 0; i < o.n; i++) { u64 v = ch_get(c, P); if (lane == 0) o.dst[i] = v & (((u64)1 << o.aux) - 1); }
-            break;
+        if (need) {                 // Challenger::duplexing -- the ONE permutation site of the kernel
+            u64 s = (u32)lane < n_in ? ib : st;
+            if (wave) s = psdw::permute(s, lane, wtab, force_redo);
+            else {
+                const u32 lo = __shfl((u32)s, lane & 15, 64), hi = __shfl((u32)(s >> 32), lane & 15, 64);
+                s = psdc::permute16(((u64)hi << 32) | lo, lane & 15, lane & ~15);
+            }
+            st = lane < 12 ? s : 0;
+            n_in = 0; n_out = 8;
+        }
+        if (post == 1 || post == 2 || post == 4) {
+            const u64 v = ch_rdlane(st, (int)n_out - 1);
+            n_out--;
+            if (post == 4) { if (lane == 0 && (u32)__clzll((long long)v) < o.n) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_POW); }
+            else if (lane == 0) o.dst[i - 1] = post == 1 ? v : (v & (((u64)1 << o.aux) - 1));     // fri_prover_query_rounds: x_index = challenge % lde_size
+        } else if (post == 3) {
+            n_out = 0;
+            if (o.dst && lane < 12) o.dst[lane] = st;
         }
     }
-    __syncthreads();
-    {
-        const u64 *src = (const u64 *)c; u64 *dst = (u64 *)gc;
-        for (u32 i = lane; i < sizeof(DevChallenger) / 8; i += 64) dst[i] = src[i];
-    }
+    if (lane < 12) gc->state[lane] = st;
+    if (lane < 8) { gc->inbuf[lane] = ib; gc->outbuf[lane] = st; }
+    if (lane == 0) { gc->n_in = n_in; gc->n_out = n_out; }
 }
 
 // PoW search: candidate w at state[pos], response = permute(state)[7]; keep the smallest accepted w.

@@ -204,3 +204,25 @@ def test_wave_permutation_round_bodies_are_what_the_generator_emits_and_pass_its
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wave_asm.py"), "--check"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_no_shipped_kernel_uses_scratch():
+    """VERDICT r3 #2a / DESIGN.md section 9: every GPU memory fault seen in three rounds had "scratch + many streams" in common, so no
+    kernel of the shipped library may use scratch (private_segment_fixed_size == 0, no dynamic stack, no spilled register) -- read from
+    the code objects' own metadata (tools/kernel_resources.py: the NT_AMDGPU_METADATA note of every gfx950 ELF inside the library's
+    .hip_fatbin).  The one exception is the debug kernel whose whole purpose is to use scratch (ZK_DEBUG_SCRATCH_PROBE)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources as KR
+    from eth_tx_proof_amd import lib as zl
+    zl.build()
+    ks = KR.kernels(zl._SO)
+    names = [k["name"] for k in ks]
+    assert len(ks) > 100 and sum("ntt_fast_kernel" in n for n in names) >= 40 and any("transcript_kernel" in n for n in names)
+    assert all("gfx950" in k["arch"] for k in ks)
+    bad = [(k["name"], k["scratch"], k["vgpr_spill"], k["sgpr_spill"]) for k in ks
+           if (k["scratch"] > 0 or k["dynamic_stack"] or k["vgpr_spill"] > 0) and "scratch_probe_kernel" not in k["name"]]
+    assert not bad, "kernels with scratch: %s" % bad
+    # two 512-thread workgroups of the NTT pass kernel per compute unit: at most 128 registers
+    assert all(k["vgpr"] + k["agpr"] <= 128 for k in ks if "ntt_fast_kernel" in k["name"])
