@@ -235,6 +235,10 @@ static void digit_widths(int k, int *w, int *np) {
     int base = k / passes, extra = k % passes;
     for (int i = 0; i < passes; i++) w[i] = base + (i < extra ? 1 : 0);
     *np = passes;
+    // experiment switch: ZK_NTT_W0 = digit width of the TILE pass of a two-pass transform (the ROW pass takes the rest, up to 12 bits:
+    // 9 + 11 at k = 20 gives the TILE pass runs of 16 elements = whole 128-byte lines instead of 8)
+    static const int w0 = getenv("ZK_NTT_W0") ? atoi(getenv("ZK_NTT_W0")) : 0;
+    if (w0 >= 4 && passes == 2 && k - w0 >= 4 && k - w0 <= 12 && w0 <= NTT_MAX_W && k - w0 >= 13 - w0) { w[0] = w0; w[1] = k - w0; }
 }
 
 template <bool DIT, bool ROW>

@@ -112,6 +112,18 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
         size_t tiles_per_block = ((size_t)1 << S) >> TL, tiles_per_col = (n >> (W + S)) * tiles_per_block;
         size_t rem;
         const u32 vcols = (u32)p.n_cols << (CS ? p.cs_bits : 0);
+        // blockIdx -> (column, tile of the column).  Column fastest (col_fast) keeps a tile position's slice of the factor table in L2
+        // while every column passes through it, but then the workgroups in flight at one time (two per CU) touch only ~5 adjacent runs
+        // of each 2^S-element stripe of a column: short bursts scattered over DRAM pages.  p.col_group = G > 0 orders the launch by groups
+        // of G columns, tile position fastest inside a group: 512 / G adjacent tiles of a column are in flight together, so whole
+        // stripes stream out of open DRAM pages, and the table slice is still shared by G columns (tools/ntt_floor.hip measures G).
+        auto split = [&](u32 unit, u32 units_per_col, u32 &c, u32 &u) {
+            if (p.col_group > 0) {
+                const u32 G = (u32)p.col_group, gsz = G * units_per_col, g = unit / gsz, idx = unit % gsz, c0 = g * G;
+                const u32 Gl = vcols - c0 < G ? vcols - c0 : G;
+                c = c0 + idx % Gl; u = idx / Gl;
+            } else { c = unit % vcols; u = unit / vcols; }
+        };
         if (p.col_fast == 2) {
             // XCD-paired order.  A TILE run is T = 2^TL adjacent elements; at W = 10 that is 8 elements = 64 bytes, HALF a 128-byte
             // line, and the workgroup holding the other half used to come n_cols workgroups later on another XCD (another L2): the
@@ -120,9 +132,9 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
             // blockIdx b and b + 8 are consecutive on one XCD: give those two the two halves of the same lines.
             const u32 b = blockIdx.x, xcd = b & 7u, m = b >> 3;
             const u32 l = (m & 1u) + 2u * (xcd + 8u * (m >> 1));
-            const u32 pair = l >> 1;
-            col = pair % vcols; rem = 2 * (size_t)(pair / vcols) + (l & 1u);
-        } else if (p.col_fast) { col = blockIdx.x % vcols; rem = blockIdx.x / vcols; }
+            u32 c, u; split(l >> 1, (u32)(tiles_per_col >> 1), c, u);
+            col = c; rem = 2 * (size_t)u + (l & 1u);
+        } else if (p.col_fast) { u32 c, u; split(blockIdx.x, (u32)tiles_per_col, c, u); col = c; rem = u; }
         else { col = blockIdx.x / tiles_per_col; rem = blockIdx.x % tiles_per_col; }
         base = ((rem / tiles_per_block) << (W + S)) + ((rem % tiles_per_block) << TL);
     }

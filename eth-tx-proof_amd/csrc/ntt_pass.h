@@ -22,6 +22,7 @@ struct PassParams {
     const u64 *store_tab;           // multiply the element stored to position pos by store_tab[pos]  (or NULL)
     int force_redo;                 // test hook: take the exact-redo branch in every workgroup (ctx->force_redo)
     int col_fast;                   // blockIdx -> (tile, column) with the column fastest, so table slices stay in L2
+    int col_group;                  // TILE passes: > 0 = groups of this many columns, tile position fastest inside a group (kernel comment)
     // coset-merged LDE (DIT, register-radix kernel only): cs_bits > 0 makes the launch cover n_cols << cs_bits virtual columns;
     // virtual column v = (column v >> cs_bits, slot v & mask) sits at column * stride + slot * sub; its factors at load_tab + slot * tab_sub
     int cs_bits;

@@ -23,7 +23,7 @@ int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &c
                         const u64 *d_public, const u64 *d_chal, const u64 *d_alphas, u64 *d_qcoeffs);
 
 // prover_quotient_jit.hip: the constraint program compiled to gfx950 code (hiprtc); same results as the interpreter
-struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u32 *redo; u32 redo_cap; u32 pad; };
+struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u64 *state; u32 redo_cap; u32 pad; };
 #define ZK_JIT_UNAVAILABLE 1        // internal: the generated kernel cannot be used (it would need scratch); not an error
 bool zk_quotient_jit_enabled(const zk_ctx *ctx, size_t L);
 int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, QJitParams &p);

@@ -4,6 +4,7 @@
 // of challenge-combined trace columns (batch inversion), Z columns are running sums.  Here
 //   h_m[row] = 1/(t[a0] + beta t[b0] + gamma) + 1/(t[a1] + beta t[b1] + gamma),   Z[row] = sum_{s >= row} sum_m h_m[s].
 // One thread = one row; reciprocals are batched 8 helper columns at a time (Montgomery's trick, one Fermat inversion).
+#include <stdlib.h>
 #include "zk_internal.h"
 #include "prover.h"
 
@@ -75,6 +76,60 @@ __global__ __launch_bounds__(256) void aux_helpers_kernel(const u64 *__restrict_
         }
     }
     rowsum[(size_t)j * n + r] = total;
+}
+
+// The same for NCH challenge sets in ONE thread (round 4): the trace cells a row's helpers need -- four per helper -- are loaded once and
+// every challenge set's reciprocals are formed from them.  The kernel above runs a grid row per challenge set and fetched every column
+// pair once per set (FETCH 2 x 623 MB for a 93-column trace, profiles/r03e_pmc...: >= 1.6 x the trace + aux bytes).  Plain helpers only
+// (no zk_helper_ext: those keep the kernel above); same field operations on the same values, so the same words.
+template <int NCH>
+__global__ __launch_bounds__(256) void aux_helpers_multi_kernel(const u64 *__restrict__ trace, size_t n, const zk_helper_desc *__restrict__ helpers, u32 H,
+                                                                const u64 *__restrict__ chal, u64 *__restrict__ aux, u64 *__restrict__ rowsum, u64 *err) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    u64 total[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) total[j] = 0;
+    for (u32 m0 = 0; m0 < H; m0 += AUX_CHUNK) {
+        u64 ta0[AUX_CHUNK], tb0[AUX_CHUNK], ta1[AUX_CHUNK], tb1[AUX_CHUNK];
+#pragma unroll
+        for (int k = 0; k < AUX_CHUNK; k++) {
+            if (m0 + k < H) {
+                const zk_helper_desc d = helpers[m0 + k];
+                ta0[k] = trace[(size_t)d.a0 * n + r]; tb0[k] = trace[(size_t)d.b0 * n + r];
+                ta1[k] = trace[(size_t)d.a1 * n + r]; tb1[k] = trace[(size_t)d.b1 * n + r];
+            } else { ta0[k] = tb0[k] = ta1[k] = tb1[k] = 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            const u64 beta = chal[2 * j], gamma = chal[2 * j + 1];
+            u64 num[AUX_CHUNK], den[AUX_CHUNK], pre[AUX_CHUNK];
+            u64 acc = 1;
+#pragma unroll
+            for (int k = 0; k < AUX_CHUNK; k++) {
+                if (m0 + k < H) {
+                    const u64 x1 = gl_add(gl_mul_add(beta, tb0[k], ta0[k]), gamma), x2 = gl_add(gl_mul_add(beta, tb1[k], ta1[k]), gamma);
+                    num[k] = gl_add(x1, x2); den[k] = gl_mul(x1, x2);
+                } else { num[k] = 0; den[k] = 1; }
+                pre[k] = acc;
+                acc = gl_mul(acc, den[k]);
+            }
+            if (acc == 0) atomicCAS((unsigned long long *)err, 0ULL, (unsigned long long)(uint32_t)ZK_ERR_ZERO_INVERSE);
+            u64 inv = gl_inv_dev(acc);
+#pragma unroll
+            for (int k = AUX_CHUNK - 1; k >= 0; k--) {
+                const u64 dinv = gl_mul(inv, pre[k]);
+                inv = gl_mul(inv, den[k]);
+                if (m0 + k < H) {
+                    const u64 h = gl_mul(num[k], dinv);
+                    aux[(size_t)(j * H + m0 + k) * n + r] = h;
+                    total[j] = gl_add(total[j], h);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; j++) rowsum[(size_t)j * n + r] = total[j];
 }
 
 // ---- suffix sums over rows: Z[r] = sum_{s >= r} rowsum[s]   (three phases, 2048 rows per workgroup)
@@ -200,8 +255,12 @@ int32_t zk_aux_columns_dev(zk_ctx *ctx, const zk_air *air, const zk_helper_desc 
     u32 nb = (u32)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     u64 *blocksum = (u64 *)ctx->alloc((size_t)nb * nch * sizeof(u64));
     if (!rowsum || !blocksum) return ZK_ERR_OOM;
-    ZK_LAUNCH(ctx, "aux_helpers", aux_helpers_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, d_trace, n, d_helpers, d_helpers_ext, H, nch, d_chal,
-              d_aux, rowsum, ctx->d_err);
+    static const int multi = getenv("ZK_AUX_MULTI") ? atoi(getenv("ZK_AUX_MULTI")) : 1;        // 0: a grid row per challenge set (A/B switch)
+    if (multi && nch == 2 && !d_helpers_ext)
+        ZK_LAUNCH(ctx, "aux_helpers", aux_helpers_multi_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_trace, n, d_helpers, H, d_chal, d_aux, rowsum, ctx->d_err);
+    else
+        ZK_LAUNCH(ctx, "aux_helpers", aux_helpers_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, d_trace, n, d_helpers, d_helpers_ext, H, nch, d_chal,
+                  d_aux, rowsum, ctx->d_err);
     ZK_LAUNCH(ctx, "aux_scan_sums", scan_block_sums_kernel, dim3(nb, nch), dim3(256), 0, (const u64 *)rowsum, n, blocksum);
     ZK_LAUNCH(ctx, "aux_scan_suffix", scan_block_suffix_kernel, dim3(nch), dim3(64), 0, blocksum, nb);
     ZK_LAUNCH(ctx, "aux_scan_final", scan_final_kernel, dim3(nb, nch), dim3(256), 0, (const u64 *)rowsum, n, (const u64 *)blocksum,

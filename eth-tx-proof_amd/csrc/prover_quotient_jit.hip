@@ -83,105 +83,137 @@ struct Gen {
 };
 
 // Wide AIRs (thousands of instructions): ONE straight-line function makes hipcc's time grow with the square of its length (430 columns /
-// 2 191 instructions: 79 s; 2 431 columns / 10 195: more than half an hour).  Above JIT_CHUNK_MIN instructions the program is cut into
-// chunks of JIT_CHUNK instructions, each a separate non-inlined device function that takes the few values alive at a cut -- the
-// program's registers (at most 24 by the bytecode's own rule), the accumulators, the row's selectors -- through memory and loads the
-// columns it touches itself.  Compile time becomes linear (2 431 columns: about a minute), the run-time cost is a few dozen scratch
-// accesses per chunk.
-#define JIT_CHUNK_MIN 1536u
-#define JIT_CHUNK 256u
+// 2 191 instructions: 79 s; 2 431 columns / 10 195: more than half an hour), and with the basic-block fences that keep its loads in place
+// hipcc gives up on the sticky word of glx<false> ("illegal VGPR to SGPR copy").  Rounds 2-3 cut such programs into non-inlined device
+// functions that took the live values through memory: compile time became linear, but calls mean a stack -- scratch on every launch,
+// the one thing every GPU memory fault of three rounds had in common.  Round 4: above JIT_SEG_MIN instructions the
+// program becomes a SEQUENCE of kernels of at most JIT_SEG instructions, exactly like the gate programs of the Plonk half below: kernel k
+// hands the accumulators and the program registers still alive at its cut (liveness analysis; a cut is moved, within JIT_SEG_SLACK
+// instructions, to where the fewest are) to kernel k + 1 through a per-launch state buffer [slot][point] in HBM.  Ping-pong halves: a
+// kernel reads one half and writes the other, so its exact twin (run by a wave whose sticky word came up) finds its inputs untouched.
+// No calls, no stack, no scratch; every column a kernel touches is loaded by that kernel.
+#define JIT_SEG_MIN 1536u
+#define JIT_SEG 768u
+#define JIT_SEG_SLACK 192u
 #define QJIT_FENCE 48u
-static std::string generate_chunked(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname, bool standalone) {
+struct SegPlan { std::vector<u32> cut; std::vector<std::vector<u32>> live; u32 max_live = 0; };   // segment k = [cut[k], cut[k+1]); live[k]: registers alive at cut[k+1]
+static u32 seg_min() {
+    static const u32 v = getenv("ZK_QJIT_SEG_MIN") ? (u32)atoi(getenv("ZK_QJIT_SEG_MIN")) : JIT_SEG_MIN;      // test / experiment switch
+    return v;
+}
+static SegPlan seg_plan(const zk_air *air, u32 seg, u32 slack) {
+    const u32 n = air->n_instrs, NR = air->n_regs ? air->n_regs : 1;
+    // live_before[pc]: registers read at or after pc before being written (backward scan)
+    std::vector<std::vector<char>> lb(n + 1, std::vector<char>(NR, 0));
+    for (u32 pc = n; pc-- > 0;) {
+        lb[pc] = lb[pc + 1];
+        const zk_instr &in = air->instrs[pc];
+        if (in.op <= ZK_OP_MUL) lb[pc][in.dst & 0xFFFFFF] = 0;
+        const u32 ops[2] = {in.a, in.b};
+        for (int q = 0; q < (in.op <= ZK_OP_MUL ? 2 : 1); q++) if ((ops[q] >> 24) == ZK_OPND_REG) lb[pc][ops[q] & 0xFFFFFF] = 1;
+    }
+    auto count = [&](u32 pc) { u32 c = 0; for (char b : lb[pc]) c += b; return c; };
+    SegPlan pl;
+    pl.cut.push_back(0);
+    while (n - pl.cut.back() > seg) {
+        const u32 hi = pl.cut.back() + seg, lo = hi - slack;
+        u32 best = hi;
+        for (u32 pc = hi; pc >= lo; pc--) if (count(pc) < count(best)) best = pc;       // the latest cut with the fewest live registers
+        pl.cut.push_back(best);
+    }
+    pl.cut.push_back(n);
+    for (size_t k = 0; k + 1 < pl.cut.size(); k++) {
+        std::vector<u32> lv;
+        if (k + 2 < pl.cut.size()) for (u32 r = 0; r < NR; r++) if (lb[pl.cut[k + 1]][r]) lv.push_back(r);
+        if (lv.size() > pl.max_live) pl.max_live = (u32)lv.size();
+        pl.live.push_back(lv);
+    }
+    return pl;
+}
+static const char QJIT_PARAMS_SRC[] =
+    "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u64 *state; u32 redo_cap; u32 pad; };\n";
+
+// one instruction of the program as source text (shared by the single-kernel and the segmented form)
+static void emit_instr(Gen &g, const zk_instr &in, u32 nch) {
+    std::string a = g.opnd(in.a);
+    if (in.op <= ZK_OP_MUL) {
+        std::string b = g.opnd(in.b);
+        appendf(g.body, "    r%u = %s(%s, %s);\n", in.dst & 0xFFFFFF, in.op == ZK_OP_ADD ? "gl_add" : in.op == ZK_OP_SUB ? "gl_sub" : "g.mul", a.c_str(), b.c_str());
+    } else {
+        const char *f = in.op == ZK_OP_EMIT_TRANSITION ? "z_last" : in.op == ZK_OP_EMIT_FIRST ? "l_first" : in.op == ZK_OP_EMIT_LAST ? "l_last" : nullptr;
+        if (f) appendf(g.body, "    { const u64 c = g.mul(%s, %s);", a.c_str(), f);
+        else appendf(g.body, "    { const u64 c = %s;", a.c_str());
+        for (u32 j = 0; j < nch; j++) appendf(g.body, " acc%u = g.mul_add(acc%u, al%u, c);", j, j, j);
+        g.body += " }\n";
+    }
+}
+
+// n_kernels / n_state: how many kernels the program becomes (names kname_0 .. kname_{n-1}) and how many state words per point ONE half
+// of the state buffer holds (accumulators + the most registers alive at a cut)
+static std::string generate_segmented(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname, bool standalone, u32 *n_kernels, u32 *n_state) {
+    const SegPlan pl = seg_plan(air, JIT_SEG, JIT_SEG_SLACK);
+    const u32 K = (u32)pl.cut.size() - 1, NS = nch + pl.max_live, NR = air->n_regs ? air->n_regs : 1;
+    if (n_kernels) *n_kernels = K;
+    if (n_state) *n_state = NS;
     std::string s;
-    if (standalone) {
-        s += "#include \"gl64.cuh\"\n";
-        s += "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u32 *redo; u32 redo_cap; u32 pad; };\n";
-    }
-    const u32 NR = air->n_regs ? air->n_regs : 1;
-    u32 n_chunks = 0;
-    for (u32 pc0 = 0; pc0 < air->n_instrs; pc0 += JIT_CHUNK, n_chunks++) {
-        Gen g; g.air = air; g.C = C; g.A = A;
+    if (standalone) { s += "#include \"gl64.cuh\"\n"; s += QJIT_PARAMS_SRC; }
+    for (u32 k = 0; k < K; k++) {
+        Gen g; g.air = air; g.C = C; g.A = A; g.fenced = true;
         g.have_l.assign(C + A, 0); g.have_n.assign(C + A, 0); g.have_pub.assign(air->n_public_inputs + 1, 0);
-        const u32 pc1 = pc0 + JIT_CHUNK < air->n_instrs ? pc0 + JIT_CHUNK : air->n_instrs;
-        for (u32 pc = pc0; pc < pc1; pc++) {
-            const zk_instr &in = air->instrs[pc];
-            std::string a = g.opnd(in.a);
-            if (in.op <= ZK_OP_MUL) {
-                std::string b = g.opnd(in.b);
-                appendf(g.body, "    r%u = %s(%s, %s);\n", in.dst & 0xFFFFFF, in.op == ZK_OP_ADD ? "gl_add" : in.op == ZK_OP_SUB ? "gl_sub" : "g.mul", a.c_str(), b.c_str());
-            } else {
-                const char *f = in.op == ZK_OP_EMIT_TRANSITION ? "z_last" : in.op == ZK_OP_EMIT_FIRST ? "l_first" : in.op == ZK_OP_EMIT_LAST ? "l_last" : nullptr;
-                if (f) appendf(g.body, "    { const u64 c = g.mul(%s, %s);", a.c_str(), f);
-                else appendf(g.body, "    { const u64 c = %s;", a.c_str());
-                for (u32 j = 0; j < nch; j++) appendf(g.body, " acc%u = g.mul_add(acc%u, al%u, c);", j, j, j);
-                g.body += " }\n";
-            }
+        for (u32 pc = pl.cut[k]; pc < pl.cut[k + 1]; pc++) {
+            if (pc > pl.cut[k] && (pc - pl.cut[k]) % QJIT_FENCE == 0)
+                appendf(g.body, "    asm volatile(\"\" : \"+v\"(tp), \"+v\"(tn), \"+v\"(ap_), \"+v\"(an));\n    if (p.redo_cap == 0x7FFF0000u + %uu) return;\n", pc);
+            emit_instr(g, air->instrs[pc], nch);
         }
-        appendf(s, "template <bool EX> __device__ __noinline__ u64 %s_c%u(const u64 *__restrict__ trace_lde, const u64 *__restrict__ aux_lde, const u64 *__restrict__ pubv, "
-                   "const u64 *__restrict__ chalv, u64 L_, u64 s, u64 sn, u64 z_last, u64 l_first, u64 l_last, const u64 *al_, u64 *r_, u64 *acc_) {\n", kname, n_chunks);
-        s += "    glx<EX> g; g.fl = 0;\n";
-        s += "    const struct { const u64 *trace_lde, *aux_lde, *pub, *chal; u64 L; } p = {trace_lde, aux_lde, pubv, chalv, L_};\n";
-        for (u32 r = 0; r < NR; r++) appendf(s, "    u64 r%u = r_[%u];\n", r, r);
-        for (u32 j = 0; j < nch; j++) appendf(s, "    u64 acc%u = acc_[%u]; const u64 al%u = al_[%u];\n", j, j, j, j);
+        appendf(s, "// instructions [%u, %u)\nextern \"C\" __global__ __launch_bounds__(256) void %s_%u(QJitParams p) {\n", pl.cut[k], pl.cut[k + 1], kname, k);
+        s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
+        s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
+        appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
+        appendf(s, "    const u64 *sin = p.state + %s + s; u64 *sout = p.state + %s + s;\n", (k & 1) ? std::string("(u64)" + std::to_string(NS) + " * p.L").c_str() : "0",
+                (k & 1) ? "0" : std::string("(u64)" + std::to_string(NS) + " * p.L").c_str());
+        s += "    auto eval = [&](auto &g) {\n";
+        s += "    const u64 *tp = p.trace_lde + s, *tn = p.trace_lde + sn, *ap_ = p.aux_lde + s, *an = p.aux_lde + sn;\n    const u64 Lq = p.L;\n";
+        s += "    const u64 x = g.mul(p.xA[i & 2047], p.xB[i >> 11]);\n    const u64 z_last = gl_sub(x, p.last_inv);\n";
+        s += "    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];\n";
+        for (u32 j = 0; j < nch; j++) {
+            if (k == 0) appendf(s, "    u64 acc%u = 0; const u64 al%u = p.alphas[%u];\n", j, j, j);
+            else appendf(s, "    u64 acc%u = sin[%uull * Lq]; const u64 al%u = p.alphas[%u];\n", j, j, j, j);
+        }
+        for (u32 r = 0; r < NR; r++) appendf(s, "    u64 r%u = 0;\n", r);
+        if (k > 0) for (size_t q = 0; q < pl.live[k - 1].size(); q++) appendf(s, "    r%u = sin[%lluull * Lq];\n", pl.live[k - 1][q], (unsigned long long)(nch + q));
         s += g.body;
-        for (u32 r = 0; r < NR; r++) appendf(s, "    r_[%u] = r%u;\n", r, r);
-        for (u32 j = 0; j < nch; j++) appendf(s, "    acc_[%u] = acc%u;\n", j, j);
-        s += "    return g.fl;\n}\n";
+        if (k + 1 == K) {
+            appendf(s, "    const u64 zi = p.zh_inv[i & %uu];\n", (1u << rate_bits) - 1);
+            for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = g.mul(acc%u, zi);\n", j, j);
+        } else {
+            for (u32 j = 0; j < nch; j++) appendf(s, "    sout[%uull * Lq] = acc%u;\n", j, j);
+            for (size_t q = 0; q < pl.live[k].size(); q++) appendf(s, "    sout[%lluull * Lq] = r%u;\n", (unsigned long long)(nch + q), pl.live[k][q]);
+        }
+        s += "    };\n";
+        s += "    glx<false> gf; gf.fl = 0;\n    eval(gf);\n";
+        s += "    if ((gf.fl != 0) | p.force) { glx<true> ge; ge.fl = 0; eval(ge); }\n";
+        s += "}\n";
     }
-    appendf(s, "template <bool EX> __device__ __forceinline__ u64 %s_run(const QJitParams &p, u64 s, u32 i, u64 sn) {\n", kname);
-    s += "    glx<EX> g; g.fl = 0;\n";
-    s += "    const u64 x = g.mul(p.xA[i & 2047], p.xB[i >> 11]);\n    const u64 z_last = gl_sub(x, p.last_inv);\n";
-    s += "    const u64 l_first = p.lag[s], l_last = p.lag[p.L + s];\n";
-    appendf(s, "    u64 rr[%u], ac[%u], alv[%u];\n", NR, nch, nch);
-    for (u32 r = 0; r < NR; r++) appendf(s, "    rr[%u] = 0;\n", r);
-    for (u32 j = 0; j < nch; j++) appendf(s, "    ac[%u] = 0; alv[%u] = p.alphas[%u];\n", j, j, j);
-    s += "    u64 fl = 0;\n";
-    for (u32 k = 0; k < n_chunks; k++)
-        appendf(s, "    fl |= %s_c%u<EX>(p.trace_lde, p.aux_lde, p.pub, p.chal, p.L, s, sn, z_last, l_first, l_last, alv, rr, ac);\n", kname, k);
-    s += "    u64 zi = p.zh_inv[0];\n";
-    appendf(s, "    { const u32 zsel = i & %uu;\n", (1u << rate_bits) - 1);
-    for (u32 j = 1; j < (1u << rate_bits); j++) appendf(s, "      zi = zsel == %uu ? p.zh_inv[%u] : zi;\n", j, j);
-    s += "    }\n";
-    for (u32 j = 0; j < nch; j++) appendf(s, "    p.out[%uull * p.L + s] = g.mul(ac[%u], zi);\n", j, j);
-    s += "    return g.fl | fl;\n}\n";
-    appendf(s, "extern \"C\" __global__ __launch_bounds__(256) void %s(QJitParams p) {\n", kname);
-    s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
-    s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
-    appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
-    appendf(s, "    const u64 f = %s_run<false>(p, s, i, sn);\n", kname);
-    appendf(s, "    if ((f != 0) | p.force) %s_run<true>(p, s, i, sn);\n}\n", kname);
     return s;
 }
 
-std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname = "quotient_jit", bool standalone = true) {
-    if (air->n_instrs >= JIT_CHUNK_MIN) return generate_chunked(air, C, A, nch, rate_bits, kname, standalone);
+std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname = "quotient_jit", bool standalone = true,
+                     u32 *n_kernels = nullptr, u32 *n_state = nullptr) {
+    if (air->n_instrs >= seg_min()) return generate_segmented(air, C, A, nch, rate_bits, kname, standalone, n_kernels, n_state);
+    if (n_kernels) *n_kernels = 1;
+    if (n_state) *n_state = 0;
     Gen g; g.air = air; g.C = C; g.A = A; g.fenced = true;
     g.have_l.assign(C + A, 0); g.have_n.assign(C + A, 0); g.have_pub.assign(air->n_public_inputs + 1, 0);
     for (u32 pc = 0; pc < air->n_instrs; pc++) {
-        const zk_instr &in = air->instrs[pc];
         // as in the gate kernels of the Plonk half: every QJIT_FENCE instructions the column base pointers pass through an empty asm and
         // an undecidable never-taken branch ends the basic block, so that hipcc cannot pull every column load to the top of the kernel
         // (93 + 40 columns, local and next rows: 163 SGPRs spilled to VGPR lanes for the hoisted offsets before, 22 now)
         if (pc && pc % QJIT_FENCE == 0)
             appendf(g.body, "    asm volatile(\"\" : \"+v\"(tp), \"+v\"(tn), \"+v\"(ap_), \"+v\"(an));\n    if (p.redo_cap == 0x7FFF0000u + %uu) return;\n", pc);
-        std::string a = g.opnd(in.a);
-        if (in.op <= ZK_OP_MUL) {
-            std::string b = g.opnd(in.b);
-            appendf(g.body, "    r%u = %s(%s, %s);\n", in.dst & 0xFFFFFF, in.op == ZK_OP_ADD ? "gl_add" : in.op == ZK_OP_SUB ? "gl_sub" : "g.mul",
-                    a.c_str(), b.c_str());
-        } else {
-            const char *f = in.op == ZK_OP_EMIT_TRANSITION ? "z_last" : in.op == ZK_OP_EMIT_FIRST ? "l_first" : in.op == ZK_OP_EMIT_LAST ? "l_last" : nullptr;
-            if (f) appendf(g.body, "    { const u64 c = g.mul(%s, %s);", a.c_str(), f);
-            else appendf(g.body, "    { const u64 c = %s;", a.c_str());
-            for (u32 j = 0; j < nch; j++) appendf(g.body, " acc%u = g.mul_add(acc%u, al%u, c);", j, j, j);
-            g.body += " }\n";
-        }
+        emit_instr(g, air->instrs[pc], nch);
     }
     std::string s;
-    if (standalone) {
-        s += "#include \"gl64.cuh\"\n";
-        s += "struct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u32 *redo; u32 redo_cap; u32 pad; };\n";
-    }
+    if (standalone) { s += "#include \"gl64.cuh\"\n"; s += QJIT_PARAMS_SRC; }
     appendf(s, "extern \"C\" __global__ __launch_bounds__(256) void %s(QJitParams p) {\n", kname);
     s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
     s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
@@ -229,36 +261,8 @@ static const char PLK_PARAMS_SRC[] =
 #define PLK_GEN_VERSION 8u
 
 // where the program is cut and which registers cross each cut
-struct PlkPlan { std::vector<u32> cut; std::vector<std::vector<u32>> live; u32 max_live = 0; };   // segment k = [cut[k], cut[k+1]); live[k]: registers alive at cut[k+1]
-static PlkPlan plonk_plan(const zk_air *air) {
-    const u32 n = air->n_instrs, NR = air->n_regs ? air->n_regs : 1;
-    // live_before[pc]: registers read at or after pc before being written (backward scan)
-    std::vector<std::vector<char>> lb(n + 1, std::vector<char>(NR, 0));
-    for (u32 pc = n; pc-- > 0;) {
-        lb[pc] = lb[pc + 1];
-        const zk_instr &in = air->instrs[pc];
-        if (in.op <= ZK_OP_MUL) lb[pc][in.dst & 0xFFFFFF] = 0;
-        const u32 ops[2] = {in.a, in.b};
-        for (int q = 0; q < (in.op <= ZK_OP_MUL ? 2 : 1); q++) if ((ops[q] >> 24) == ZK_OPND_REG) lb[pc][ops[q] & 0xFFFFFF] = 1;
-    }
-    auto count = [&](u32 pc) { u32 c = 0; for (char b : lb[pc]) c += b; return c; };
-    PlkPlan pl;
-    pl.cut.push_back(0);
-    while (n - pl.cut.back() > PLK_SEG) {
-        const u32 hi = pl.cut.back() + PLK_SEG, lo = hi - PLK_SEG_SLACK;
-        u32 best = hi;
-        for (u32 pc = hi; pc >= lo; pc--) if (count(pc) < count(best)) best = pc;       // the latest cut with the fewest live registers
-        pl.cut.push_back(best);
-    }
-    pl.cut.push_back(n);
-    for (size_t k = 0; k + 1 < pl.cut.size(); k++) {
-        std::vector<u32> lv;
-        if (k + 2 < pl.cut.size()) for (u32 r = 0; r < NR; r++) if (lb[pl.cut[k + 1]][r]) lv.push_back(r);
-        if (lv.size() > pl.max_live) pl.max_live = (u32)lv.size();
-        pl.live.push_back(lv);
-    }
-    return pl;
-}
+using PlkPlan = SegPlan;
+static PlkPlan plonk_plan(const zk_air *air) { return seg_plan(air, PLK_SEG, PLK_SEG_SLACK); }
 
 struct PGen {
     const zk_air *air; u32 W;
@@ -500,7 +504,9 @@ bool zk_quotient_jit_enabled(const zk_ctx *ctx, size_t L) {
     return ctx->quotient_jit_mode >= 0 || ctx->quotient_aot;
 }
 
-static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k);
+// the kernel(s) of one constraint program: one function, or the sequence of a segmented program with its state slots per point
+struct QuotKernels { std::vector<hipFunction_t> fns; u32 n_state = 0; };
+static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, QuotKernels &k);
 
 int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, QJitParams &p) {
     if (ctx->quotient_aot) {
@@ -519,14 +525,25 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
     }
     if (ctx->quotient_jit_mode < 0) return ZK_JIT_UNAVAILABLE;
     const bool worth_compiling = ctx->quotient_jit_mode == 2 || (ctx->quotient_jit_mode == 1 && p.L >= ((size_t)1 << ctx->quotient_jit_min_log));
-    JitKernel k;
+    QuotKernels k;
     int32_t rc = jit_get(ctx, air, C, A, nch, rate_bits, worth_compiling, k);
     if (rc != ZK_OK) return rc;
-    if (!k.fn) return ZK_JIT_UNAVAILABLE;
+    if (k.fns.empty()) return ZK_JIT_UNAVAILABLE;
+    // a segmented program hands accumulators and live registers from kernel to kernel through a state buffer [half][slot][point]
+    u64 *state = nullptr;
+    if (k.fns.size() > 1) {
+        state = (u64 *)ctx->alloc((size_t)2 * k.n_state * p.L * sizeof(u64));
+        if (!state) return ctx->fail(ZK_ERR_OOM, "quotient jit: state buffer of the kernel sequence");
+    }
+    p.state = state;
     void *args[] = {&p};
     const unsigned blocks = (unsigned)((p.L + 255) / 256);
-    hipError_t e;
-    { ProfScope ps(ctx, "quotient_eval"); e = hipModuleLaunchKernel(k.fn, blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr); }
+    hipError_t e = hipSuccess;
+    {
+        ProfScope ps(ctx, "quotient_eval");
+        for (size_t j = 0; j < k.fns.size() && e == hipSuccess; j++) e = hipModuleLaunchKernel(k.fns[j], blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+    }
+    ctx->release(state);                    // stream-ordered
     if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: launch failed");
     return ZK_OK;
 }
@@ -545,7 +562,7 @@ extern "C" int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *c
         if (zk_air_validate(air, cfg->num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "prover_state_prepare: malformed AIR");
         const u32 nch = cfg->num_challenges, A = zk_air_n_aux(air, nch);
         if (ctx->quotient_aot && zk_quotient_aot_lookup(fnv1a(air_key(air, air->n_trace_cols, A, nch, cfg->rate_bits)))) continue;   // built with the library
-        JitKernel k;
+        QuotKernels k;
         int32_t rc = jit_get(ctx, air, air->n_trace_cols, A, nch, cfg->rate_bits, true, k);
         if (rc != ZK_OK) return rc;
     }
@@ -618,7 +635,7 @@ static int32_t jit_compile_cached(zk_ctx *ctx, const std::string &base_key, bool
     if (!may_compile) { k = JitKernel(); return ZK_OK; }
     std::string disk_key = base_key;
     {
-        const u64 ver[2] = {5 /* generator version */, fnv1a(GL64_SRC)};
+        const u64 ver[2] = {6 /* generator version */, fnv1a(GL64_SRC)};
         disk_key.append((const char *)ver, sizeof ver);
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) disk_key.append(pr.gcnArchName);
@@ -683,9 +700,44 @@ static int32_t jit_compile_cached(zk_ctx *ctx, const std::string &base_key, bool
     return ZK_OK;
 }
 
-static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, JitKernel &k) {
+static std::mutex g_qmu;
+static std::map<std::string, QuotKernels> g_qcache;        // (program, device) -> its kernels, once they exist
+static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, bool may_compile, QuotKernels &out) {
+    out = QuotKernels();
+    std::string qkey = air_key(air, C, A, nch, rate_bits);
+    { u32 dev = (u32)ctx->device; qkey.append((const char *)&dev, sizeof dev); }
+    {
+        std::lock_guard<std::mutex> lk(g_qmu);
+        auto it = g_qcache.find(qkey);
+        if (it != g_qcache.end()) { out = it->second; return ZK_OK; }
+    }
     QJitParams z = {};
-    return jit_compile_cached(ctx, air_key(air, C, A, nch, rate_bits), may_compile, [&]() { return generate(air, C, A, nch, rate_bits); }, "quotient_jit", &z, k);
+    JitKernel k;
+    const bool seg = air->n_instrs >= seg_min();
+    u32 K = 1, ns = 0;
+    std::string key = air_key(air, C, A, nch, rate_bits);
+    if (seg) {
+        const SegPlan pl = seg_plan(air, JIT_SEG, JIT_SEG_SLACK);           // the plan alone: cheap next to a compile
+        K = (u32)pl.cut.size() - 1; ns = nch + pl.max_live;
+        const u32 hdr[4] = {0x53454751u /* "SEGQ" */, JIT_SEG, JIT_SEG_SLACK, QJIT_FENCE};
+        key.append((const char *)hdr, sizeof hdr);
+    }
+    int32_t rc = jit_compile_cached(ctx, key, may_compile, [&]() { return generate(air, C, A, nch, rate_bits); }, seg ? "quotient_jit_0" : "quotient_jit", &z, k);
+    if (rc != ZK_OK || !k.fn) return rc;
+    out.fns.push_back(k.fn); out.n_state = ns;
+    for (u32 j = 1; j < K; j++) {
+        char nm[64]; snprintf(nm, sizeof nm, "quotient_jit_%u", j);
+        hipFunction_t f = nullptr;
+        if (hipModuleGetFunction(&f, k.mod, nm) != hipSuccess) { out = QuotKernels(); return ctx->fail(ZK_ERR_HIP, "quotient jit: a kernel of the sequence is missing from the module"); }
+        // as for the first kernel (jit_compile_cached): no scratch if so required, and one settling launch with L = 0
+        static const bool no_scratch = getenv("ZK_QUOTIENT_JIT_NO_SCRATCH") && atoi(getenv("ZK_QUOTIENT_JIT_NO_SCRATCH"));
+        int scratch = 0;
+        if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) != hipSuccess || (no_scratch && scratch > 0)) { out = QuotKernels(); return ZK_OK; }
+        out.fns.push_back(f);
+    }
+    std::lock_guard<std::mutex> lk(g_qmu);
+    g_qcache[qkey] = out;
+    return ZK_OK;
 }
 
 // ---- Plonk gate programs: build-time registry (prover_plonk_aot.hip, tools/gen_aot_quotient.py), else hiprtc at zk_plonk_setup

@@ -40,7 +40,6 @@ __global__ __launch_bounds__(64) void transcript_kernel(DevChallenger *gc, TOpLi
         const TOp o = ops.op[k];
         bool need = false;          // duplexing in this step
         int post = 0;               // 1: pop a challenge -> dst[i - 1]   2: ... masked to aux bits   3: compact   4: PoW response
-        u64 w_pow = 0;
         switch (o.kind) {
         case TOP_INIT:
             st = 0; n_in = 0; n_out = 0; k++; i = 0;

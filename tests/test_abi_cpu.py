@@ -160,11 +160,13 @@ def test_air_validate_refuses_malformed_programs(zk):
     assert L.zk_quotient_kernel_source(mk(bad_programs[0]).ref, C.c_uint32(2), C.c_uint32(1), None, C.c_size_t(0), C.byref(ln), C.byref(h)) == -1
 
 
-def test_chunked_constraint_kernel_source_compiles_for_gfx950(zk, tmp_path):
-    """A wide AIR (430 columns, 2 191 instructions) makes the generator cut the program into non-inlined chunk functions
-    (prover_quotient_jit.hip generate_chunked); the source it emits must be valid HIP for gfx950 -- cross-compiled here with hipcc, the
-    compiler hiprtc wraps on the GPU box (where tests/test_gpu_pieces.py compares the kernel's output with the oracle's)."""
-    import os, shutil, subprocess
+def test_segmented_constraint_kernel_source_compiles_for_gfx950_without_scratch(zk, tmp_path):
+    """A wide AIR (430 columns, 2 191 instructions) makes the generator cut the program into a SEQUENCE of call-free kernels that hand the
+    accumulators and live registers on through a state buffer (prover_quotient_jit.hip generate_segmented; rounds 2-3 used non-inlined
+    chunk functions, i.e. a stack = scratch).  The source must be valid HIP for gfx950 -- cross-compiled here with hipcc, the compiler
+    hiprtc wraps on the GPU box (where tests/test_gpu_pieces.py compares the kernels' output with the oracle's) -- and the compiled
+    kernels must not use scratch (tools/kernel_resources.py on the object's metadata)."""
+    import os, shutil, subprocess, sys
     from eth_tx_proof_amd import air
     if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
         import pytest
@@ -176,18 +178,24 @@ def test_chunked_constraint_kernel_source_compiles_for_gfx950(zk, tmp_path):
     buf = C.create_string_buffer(ln.value + 1)
     assert L.zk_quotient_kernel_source(prog.ref, C.c_uint32(2), C.c_uint32(1), buf, C.c_size_t(ln.value + 1), C.byref(ln), C.byref(kh)) == 0
     src = buf.value.decode()
-    n_chunks = src.count("__noinline__")
-    assert n_chunks == (prog.n_instrs + 255) // 256 and "_run<false>" in src and "_run<true>" in src
+    n_kernels = src.count("__global__")
+    assert n_kernels == 3 and "__noinline__" not in src and src.count("sout[") > 0 and src.count("sin[") > 0
+    assert "quotient_aot_%016x_0(" % kh.value in src and "quotient_aot_%016x_2(" % kh.value in src
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "eth-tx-proof_amd", "csrc")
     hdr = ('#include "gl64.cuh"\nstruct QJitParams { const u64 *trace_lde, *aux_lde, *pub, *chal, *alphas, *lag, *xA, *xB; u64 *out; u64 L; '
-           'u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u32 *redo; u32 redo_cap; u32 pad; };\n')
+           'u64 last_inv; u64 zh_inv[8]; u32 lgL; u32 force; u64 *state; u32 redo_cap; u32 pad; };\n')
     f = tmp_path / "q430.hip"
     f.write_text(hdr + src)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    out = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-I" + csrc, "-c", str(f), "-o", str(tmp_path / "q430.o")],
+    obj = tmp_path / "q430.o"
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + csrc, "-c", str(f), "-o", str(obj)],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import kernel_resources as KR
+    ks = KR.kernels(str(obj))
+    assert len(ks) == 3 and all(k["scratch"] == 0 and k["vgpr_spill"] == 0 and not k["dynamic_stack"] for k in ks), ks
     # a narrow AIR keeps the single-function form (the kernels built with the library depend on that text)
     small = air.cpu_like_air(93, 19)
     assert L.zk_quotient_kernel_source(small.ref, C.c_uint32(2), C.c_uint32(1), None, C.c_size_t(0), C.byref(ln), C.byref(kh)) == 0

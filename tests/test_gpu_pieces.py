@@ -209,7 +209,7 @@ def test_fri_instance_error_paths(ctx, zk):
 def test_quotient_jit_equals_interpreter_and_oracle(zk, orc, monkeypatch, n_cols, n_helpers, log_n):
     """the constraint program compiled with hiprtc (ZK_QUOTIENT_JIT=2: always) and the bytecode interpreter (=0) produce the
     oracle's quotient polynomials bit for bit.  (430 columns = 2 191 instructions: the generator cuts programs of that length into
-    chunks, one non-inlined function each.)"""
+    a sequence of call-free kernels that pass accumulators and live registers on through a state buffer.)"""
     from eth_tx_proof_amd import air
     cfg = _cfg()
     rng = np.random.default_rng(log_n)

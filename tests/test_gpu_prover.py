@@ -422,8 +422,9 @@ def test_cfg4_all_seven_tables_at_their_real_sizes_bit_exact(ctx, zk, orc):
 
 def test_cfg4_with_prepared_constraint_kernels_bit_exact(zk, orc):
     """The seven-table unit again, this time with the prover state prepared (zk_prover_state_prepare: hiprtc compiles the constraint
-    kernels of the three wide tables -- 430, 523 and 2 431 columns, generated in chunks, about a minute and a half when nothing is
-    cached -- the narrow ones were built with the library): every table's quotient comes from compiled code, and the proof is still the
+    kernels of the three wide tables -- 430, 523 and 2 431 columns, sequences of 3 / 4 / 14 call-free kernels, about a minute and a half
+    when nothing is cached; the prover-state directory of the tree (eth-tx-proof_amd/prover_state) is used when it holds them -- the
+    narrow ones were built with the library): every table's quotient comes from compiled code, and the proof is still the
     oracle's, word for word."""
     from eth_tx_proof_amd import air
     cfg = _cfg()
@@ -434,7 +435,14 @@ def test_cfg4_with_prepared_constraint_kernels_bit_exact(zk, orc):
             prog = air.cpu_like_air(w, min(19, w // 4))
             tr, pub = orc.synth_trace(w, lg, 0x5EED0000 + 1000 * t)
             items.append((prog, lg, tr, pub))
-        zk.prover_state_prepare(c2, cfg, items)
+        import os
+        state_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eth-tx-proof_amd", "prover_state")
+        if os.path.isdir(state_dir):
+            zk.prover_state_cache_dir(state_dir)
+        try:
+            zk.prover_state_prepare(c2, cfg, items)
+        finally:
+            zk.prover_state_cache_dir(None)
         assert sum(zk.prover_state_stats()) >= 3            # compiled now, or loaded from the prover-state directory
         c2.profile(True); c2.profile_reset()
         proof = zk.prove_tables(c2, cfg, items)

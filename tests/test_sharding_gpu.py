@@ -135,3 +135,26 @@ def test_prover_input_prove_over_two_ranks(tmp_path):
                           "--master-port", "29688", str(script)], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "LEADER_OK" in out.stdout
+
+
+def test_bench_two_ranks_at_configs4_full_unit_size(tmp_path):
+    """BASELINE configs[4] rehearsed at FULL unit size: 16 units of 2^20 rows x 93 + 40 columns -- two rank processes on
+    this one card (gloo), four units in flight each, two steps -- through bench.py's N > 1 path: sharded units, per-proof hand-off to rank
+    0 while the next units are proved, max-over-ranks timing.  The line carries what the first run on a whole node will be read by:
+    every rank's own proofs/s, the exposed part of the hand-off, and the timed proof against the oracle's committed digest."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29699", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--inflight", "4",
+                          "--log-n", "20", "--no-pcie", "--no-cpu-baseline", "--no-profile", "--no-prove-root"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["units_per_step_per_gpu"] == 4
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["units"] == 8 and r["proofs_per_s"] > 0 for r in line["per_rank"])
+    assert line["handoff"]["MB_into_rank0"] > 0 and line["handoff"]["exposed_ms"] >= 0
+    assert line["timed_proof_check"]["identical_to_oracle"] is True
+    art = os.environ.get("ZK_TEST_ARTIFACTS")
+    if art:
+        os.makedirs(art, exist_ok=True)
+        open(os.path.join(art, "bench_2ranks_full_size_gloo_rehearsal.json"), "w").write(json.dumps(line) + "\n")

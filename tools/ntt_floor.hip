@@ -8,7 +8,7 @@
 // pass's own occupancy (two 512-thread workgroups per CU): its run time is the floor no memory-side change can go below; mode 1 adds
 // what the LDS exchanges and their barriers cost; mode 0 - mode 1 is what the pass waits for HBM.
 // Build (three binaries, one per mode):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DNTT_FLOOR=<m> -Ieth-tx-proof_amd/csrc tools/ntt_floor.hip -o tools/bin/ntt_floor<m>
-// Run:  tools/bin/ntt_floor<m> [n_cols=93] [reps=20]      -> one line per pass: us per launch, ns per element, SIMD-cycles per element
+// Run:  tools/bin/ntt_floor<m> [n_cols=93] [reps=20] [col_group=0]      -> one line per pass: us per launch, ns per element, SIMD-cycles per element
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,7 +35,7 @@ static float run(const PassParams &p, int reps, hipStream_t st) {
 }
 
 int main(int argc, char **argv) {
-    const int n_cols = argc > 1 ? atoi(argv[1]) : 93, reps = argc > 2 ? atoi(argv[2]) : 20;
+    const int n_cols = argc > 1 ? atoi(argv[1]) : 93, reps = argc > 2 ? atoi(argv[2]) : 20, col_group = argc > 3 ? atoi(argv[3]) : 0;
     const int k = 20;
     const size_t n = (size_t)1 << k;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
@@ -46,7 +46,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(in, 0, n * n_cols * 8)); CK(hipMemset(mid, 0, n * n_cols * 8)); CK(hipMemset(tab, 0, n * 8)); CK(hipMemset(rw, 0, 1024 * 8));
     hipStream_t st; CK(hipStreamCreate(&st));
     PassParams b = {};
-    b.k = k; b.W = 10; b.TL = 3; b.n_cols = n_cols; b.tw_full = rw;
+    b.k = k; b.W = 10; b.TL = 3; b.n_cols = n_cols; b.tw_full = rw; b.col_group = col_group;
     struct { const char *name; float ms; } res[4];
     { PassParams p = b; p.in = in; p.in_stride = n; p.out = mid; p.out_stride = n; p.S = 10; p.inverse = 1; p.canon_in = 1; p.store_tab = tab; p.col_fast = 2;
       res[0] = {"inverse DIF pass 1 (TILE, inter-pass factors at the store)", run<false, false, true>(p, reps, st)}; }
@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     { PassParams p = b; p.in = in; p.in_stride = n; p.out = out; p.out_stride = 2 * n; p.S = 10; p.load_tab = tab; p.permute_out = 1; p.col_fast = 2;
       res[3] = {"forward DIT pass 2 (TILE, inter-pass factors at the load, permuted store)", run<true, false, false>(p, reps, st)}; }
     CK(hipStreamSynchronize(st));
-    printf("# ntt_floor mode %d: %d columns x 2^%d, W = 10, %d SIMDs at %.2f GHz, %d launches each\n", (int)NTT_FLOOR, n_cols, k, (int)simds, ghz, reps);
+    printf("# ntt_floor mode %d: %d columns x 2^%d, W = 10, col_group %d, %d SIMDs at %.2f GHz, %d launches each\n", (int)NTT_FLOOR, n_cols, k, col_group, (int)simds, ghz, reps);
     const double elems = (double)n * n_cols;
     for (auto &r : res)
         printf("%-78s %8.1f us  %6.3f ns/element  %6.2f SIMD-cycles/element  %7.1f GB/s algorithmic\n", r.name, r.ms * 1e3, r.ms * 1e6 / elems,
