@@ -94,12 +94,16 @@ struct Gen {
 // No calls, no stack, no scratch; every column a kernel touches is loaded by that kernel.
 #define JIT_SEG_MIN 1536u
 #define JIT_SEG 768u
-#define JIT_SEG_SLACK 192u
+#define JIT_SEG_SLACK 192u       // = JIT_SEG / 4
 #define QJIT_FENCE 48u
 struct SegPlan { std::vector<u32> cut; std::vector<std::vector<u32>> live; u32 max_live = 0; };   // segment k = [cut[k], cut[k+1]); live[k]: registers alive at cut[k+1]
 static u32 seg_min() {
     static const u32 v = getenv("ZK_QJIT_SEG_MIN") ? (u32)atoi(getenv("ZK_QJIT_SEG_MIN")) : JIT_SEG_MIN;      // test / experiment switch
     return v;
+}
+static u32 seg_len() {
+    static const u32 v = getenv("ZK_QJIT_SEG") ? (u32)atoi(getenv("ZK_QJIT_SEG")) : JIT_SEG;                  // experiment switch
+    return v < 64 ? 64 : v;
 }
 static SegPlan seg_plan(const zk_air *air, u32 seg, u32 slack) {
     const u32 n = air->n_instrs, NR = air->n_regs ? air->n_regs : 1;
@@ -151,7 +155,7 @@ static void emit_instr(Gen &g, const zk_instr &in, u32 nch) {
 // n_kernels / n_state: how many kernels the program becomes (names kname_0 .. kname_{n-1}) and how many state words per point ONE half
 // of the state buffer holds (accumulators + the most registers alive at a cut)
 static std::string generate_segmented(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname, bool standalone, u32 *n_kernels, u32 *n_state) {
-    const SegPlan pl = seg_plan(air, JIT_SEG, JIT_SEG_SLACK);
+    const SegPlan pl = seg_plan(air, seg_len(), seg_len() / 4);
     const u32 K = (u32)pl.cut.size() - 1, NS = nch + pl.max_live, NR = air->n_regs ? air->n_regs : 1;
     if (n_kernels) *n_kernels = K;
     if (n_state) *n_state = NS;
@@ -717,9 +721,9 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
     u32 K = 1, ns = 0;
     std::string key = air_key(air, C, A, nch, rate_bits);
     if (seg) {
-        const SegPlan pl = seg_plan(air, JIT_SEG, JIT_SEG_SLACK);           // the plan alone: cheap next to a compile
+        const SegPlan pl = seg_plan(air, seg_len(), seg_len() / 4);         // the plan alone: cheap next to a compile
         K = (u32)pl.cut.size() - 1; ns = nch + pl.max_live;
-        const u32 hdr[4] = {0x53454751u /* "SEGQ" */, JIT_SEG, JIT_SEG_SLACK, QJIT_FENCE};
+        const u32 hdr[4] = {0x53454751u /* "SEGQ" */, seg_len(), seg_len() / 4, QJIT_FENCE};
         key.append((const char *)hdr, sizeof hdr);
     }
     int32_t rc = jit_compile_cached(ctx, key, may_compile, [&]() { return generate(air, C, A, nch, rate_bits); }, seg ? "quotient_jit_0" : "quotient_jit", &z, k);
