@@ -703,11 +703,12 @@ def main():
         c.close()
     ctxs = []
     if rank == 0:
-        # ---- the operator's whole call: a short transaction record beside BASELINE's unit -- 8 transactions in flight x 2
-        # steps, one transaction alone split into its three stages, root proof and AllProof against the oracle's committed digests
+        # ---- the operator's whole call: a short transaction record beside BASELINE's unit -- 8 transactions in flight x 4
+        # steps (two steps are mostly ramp: 19 against 26 tx/s), one transaction alone split into its three stages, root proof and AllProof
+        # against the oracle's committed digests
         if world == 1 and args.log_n == 20 and not args.no_prove_root:
             try:
-                pr = run_prove_root(8, 2, 1, prepare=args.prepare)
+                pr = run_prove_root(8, 4, 1, prepare=args.prepare)
                 line["prove_root"] = {k: pr[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "one_tx_alone_ms", "timed_proof_check")}
                 line["prove_root"]["config"] = pr["config"]
                 line["prove_root"]["note"] = "NOT the headline (`value` above is BASELINE's unit metric); python bench.py --workload prove_root gives the long form"

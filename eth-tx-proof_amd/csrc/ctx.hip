@@ -75,9 +75,46 @@ int32_t zk_ctx::upload_small(void *d_dst, const void *src, size_t bytes) {
         if (hipMemcpyAsync(d_dst, p, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return fail(ZK_ERR_HIP, "upload_small: hipMemcpyAsync");
         return ZK_OK;
     }
-    // staging full: copy straight from the caller's memory and wait for it
-    if (hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
-        return fail(ZK_ERR_HIP, "upload_small: synchronous copy");
+    // staging full: through the bounce buffer, and wait for it
+    return copy_h2d_sync(d_dst, src, bytes);
+}
+
+// Synchronous copies between caller memory and the device.  The caller's memory is pageable as a rule (numpy arrays, std::vector): handed
+// to hipMemcpyAsync directly, the runtime pins its pages on the fly and releases them when the copy retires -- with dozens of threads doing
+// that at once (eight transactions x four contexts: Merkle roots of child proofs, public-input hashes, caps coming back) one run in 16 ended
+// in "Memory access fault by GPU" at an address inside a worker thread's malloc arena.  Every such copy now bounces through pinned memory
+// owned by the context, 4 MiB at a time; big uploads keep the double-buffered path of upload_large.
+#define ZK_IO_BYTES ((size_t)4 << 20)
+static bool io_buffer(zk_ctx *c) {
+    if (c->h_io) return true;
+    if (hipHostMalloc((void **)&c->h_io, ZK_IO_BYTES, hipHostMallocDefault) != hipSuccess) { c->h_io = nullptr; (void)hipGetLastError(); return false; }
+    return true;
+}
+int32_t zk_ctx::copy_h2d_sync(void *d_dst, const void *src, size_t bytes) {
+    if (!bytes) return ZK_OK;
+    if (bytes > 4 * ZK_IO_BYTES) {           // a trace-sized array: pinned source -> one copy, pageable -> two 32 MiB chunks in turn
+        int32_t rc = upload_large(d_dst, src, bytes, stream);
+        if (rc != ZK_OK) return rc;
+        return hipStreamSynchronize(stream) == hipSuccess ? ZK_OK : fail(ZK_ERR_HIP, "copy_h2d_sync: stream sync");
+    }
+    if (!io_buffer(this)) return fail(ZK_ERR_OOM, "copy_h2d_sync: pinned bounce buffer");
+    for (size_t off = 0; off < bytes; off += ZK_IO_BYTES) {
+        const size_t len = bytes - off < ZK_IO_BYTES ? bytes - off : ZK_IO_BYTES;
+        memcpy(h_io, (const char *)src + off, len);
+        if (hipMemcpyAsync((char *)d_dst + off, h_io, len, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            return fail(ZK_ERR_HIP, "copy_h2d_sync: copy");
+    }
+    return ZK_OK;
+}
+int32_t zk_ctx::copy_d2h_sync(void *dst, const void *d_src, size_t bytes) {
+    if (!bytes) return ZK_OK;
+    if (!io_buffer(this)) return fail(ZK_ERR_OOM, "copy_d2h_sync: pinned bounce buffer");
+    for (size_t off = 0; off < bytes; off += ZK_IO_BYTES) {
+        const size_t len = bytes - off < ZK_IO_BYTES ? bytes - off : ZK_IO_BYTES;
+        if (hipMemcpyAsync(h_io, (const char *)d_src + off, len, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            return fail(ZK_ERR_HIP, "copy_d2h_sync: copy");
+        memcpy((char *)dst + off, h_io, len);
+    }
     return ZK_OK;
 }
 
@@ -249,6 +286,7 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     hipFree(c->d_err);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_out) hipHostFree(c->h_out);
+    if (c->h_io) hipHostFree(c->h_io);
     if (c->h_packed_off) hipHostFree(c->h_packed_off);
     if (c->packed_off_done) hipEventDestroy(c->packed_off_done);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
@@ -397,15 +435,13 @@ int32_t zk_trace_upload_packed(zk_ctx *c, const void *packed, uint32_t log_n, ui
 }
 int32_t zk_dev_upload(zk_ctx *c, void *d_dst, const void *src, size_t bytes) {
     if (!c || (!d_dst && bytes) || (!src && bytes)) return ZK_ERR_INVALID_ARG;
-    HIP_TRY(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return ZK_OK;
+    hipSetDevice(c->device);
+    return c->copy_h2d_sync(d_dst, src, bytes);
 }
 int32_t zk_dev_download(zk_ctx *c, void *dst, const void *d_src, size_t bytes) {
     if (!c || (!dst && bytes) || (!d_src && bytes)) return ZK_ERR_INVALID_ARG;
-    HIP_TRY(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return ZK_OK;
+    hipSetDevice(c->device);
+    return c->copy_d2h_sync(dst, d_src, bytes);
 }
 
 void zk_stark_config_standard_fast(zk_stark_config *c) {

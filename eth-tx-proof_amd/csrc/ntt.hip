@@ -155,9 +155,8 @@ __global__ void bitrev_copy_kernel(const u64 *in, size_t in_stride, u64 *out, si
 static u64 *upload(zk_ctx *ctx, const std::vector<u64> &h) {
     u64 *d = (u64 *)ctx->alloc(h.size() * sizeof(u64));
     if (!d) return nullptr;
-    // tables are built rarely; synchronous copy keeps the host vector's lifetime trivial
-    hipMemcpyAsync(d, h.data(), h.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
-    hipStreamSynchronize(ctx->stream);
+    // tables are built rarely; a synchronous copy (through the context's pinned bounce buffer) keeps the host vector's lifetime trivial
+    if (ctx->copy_h2d_sync(d, h.data(), h.size() * sizeof(u64)) != ZK_OK) { ctx->release(d); return nullptr; }
     return d;
 }
 
