@@ -68,7 +68,9 @@ int32_t zk_profile_reset(zk_ctx *ctx);
 int32_t zk_profile_count(zk_ctx *ctx);
 int32_t zk_profile_get(zk_ctx *ctx, int32_t i, const char **name, uint64_t *launches, double *total_ms);
 
-/* Device memory for callers without HIP bindings (Rust side keeps only opaque pointers). */
+/* Device memory for callers without HIP bindings (Rust side keeps only opaque pointers).  zk_dev_upload / zk_dev_download are synchronous
+ * and accept any host memory: the library never hands pageable memory to the DMA engines -- every such copy bounces through pinned memory
+ * owned by the context. */
 int32_t zk_dev_alloc(zk_ctx *ctx, size_t bytes, void **d_ptr);
 int32_t zk_dev_free(zk_ctx *ctx, void *d_ptr);
 int32_t zk_dev_upload(zk_ctx *ctx, void *d_dst, const void *src, size_t bytes);
@@ -310,7 +312,7 @@ int32_t zk_prove_tables_notify(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t
  * ops::p_state, ops/src/lib.rs:16-18).  Here: the constraint programs of the given tables compiled to gfx950 code (hiprtc) and
  * cached for the process (and in the prover-state directory, zk_prover_state_cache_dir); without this call proofs evaluate
  * constraints with the bytecode interpreter unless the AIR's kernel was built with the library.  Every table given here is compiled,
- * whatever its size (programs of thousands of instructions are generated in chunks: minutes at most), and a compiled kernel is used
+ * whatever its size (programs of thousands of instructions become a sequence of call-free kernels: a minute or two at most), and a compiled kernel is used
  * at any table size afterwards.  Call from the thread that created the context, before handing units to worker threads.  `trace` of
  * the tables is not read. */
 int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables);
