@@ -177,6 +177,8 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
                        "shrink_chains_start_under_the_later_tables_stark_proofs": {0: "never", 1: "always"}.get(chain_overlap, "auto: with at most 2 transactions in flight (so: for one_tx_alone_ms, not in the timed region unless --inflight <= 2)"),
                        "constraint_kernels_of_the_wide_tables": ("compiled (zk_prover_state_prepare: %d by hiprtc in %.1f s, %d from the prover-state directory)" % (c1 - c0, t_prep, l1 - l0)) if do_prepare
                        else "bytecode interpreter (no prover-state files in %s and no compile inside a bench run: python bench.py --workload prove_root --prepare always writes them)" % os.path.relpath(PROVER_STATE_DIR, ROOT),
+                       "fiat_shamir_sponge": "device-resident (one-wave kernel) in the timed region; on a host thread (zk_ctx_set_host_transcript) while at most 2 transactions are in flight, "
+                                             "i.e. for one_tx_alone_ms -- the same rule as the chain overlap; identical proof words either way",
                        "recursion_witnesses": "PRECOMPUTED: one satisfying witness per stand-in circuit, held in pinned host memory, PublicInputGate cells rewritten per proof -- upstream runs plonky2's "
                                               "witness generators on the CPU for every proof; that work is NOT in this number (SURVEY.md 8f-2 leaves generators on the CPU)",
                        "parallelism": "independent transactions, 1 GPU"},

@@ -258,6 +258,7 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
     { const char *e = getenv("ZK_SYNC_LAUNCH"); if (e) c->sync_launch = atoi(e); }
     { const char *e = getenv("ZK_ALLOC_EFENCE"); if (e) c->efence = atoi(e); }
     { const char *e = getenv("ZK_QUOTIENT_JIT_MIN_LOG"); if (e) c->quotient_jit_min_log = atoi(e); }
+    { const char *e = getenv("ZK_TRANSCRIPT_HOST"); if (e) c->host_transcript = atoi(e) ? 1 : 0; }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ZK_ERR_HIP; }
@@ -275,10 +276,21 @@ int32_t zk_ctx_set_side_commit(zk_ctx *c, int32_t on) {
     return ZK_OK;
 }
 
+int32_t zk_ctx_set_host_transcript(zk_ctx *c, int32_t on) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    if (c->host_transcript == (on ? 1 : 0)) return ZK_OK;
+    // between proofs only: the two challengers keep their sponge states in different places
+    hipStreamSynchronize(c->stream);
+    zk_host_transcript_begin_proof(c);
+    c->host_transcript = on ? 1 : 0;
+    return ZK_OK;
+}
+
 int32_t zk_ctx_destroy(zk_ctx *c) {
     if (!c) return ZK_ERR_INVALID_ARG;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    zk_host_transcript_destroy(c);
     if (c->side) { zk_ctx_destroy(c->side); c->side = nullptr; }
     c->prof_flush();
     for (auto e : c->event_pool) hipEventDestroy(e);

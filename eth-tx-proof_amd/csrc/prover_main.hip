@@ -165,6 +165,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
     // small host objects go up through the context's pinned staging (zk_ctx::upload_small); the proof comes back through
     // its pinned download buffer.  The staging is reused from the start: the previous proof of this context has been waited for.
     ctx->h_stage_used = 0;
+    zk_host_transcript_begin_proof(ctx);
     u64 *h_out = (u64 *)ctx->pinned_out((total + 1) * sizeof(u64));
     if (!h_out) return ctx->fail(ZK_ERR_OOM, "prove: pinned download buffer");
 
@@ -376,5 +377,6 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         ctx->fail(rc, "prove: device-side check failed");
         hipMemsetAsync(ctx->d_err, 0, sizeof(u64), ctx->stream);
     }
+    if (const int32_t he = zk_host_transcript_take_error(ctx)) { if (rc == ZK_OK) { rc = he; ctx->fail(rc, "prove: host-side transcript check failed"); } }
     return rc;
 }

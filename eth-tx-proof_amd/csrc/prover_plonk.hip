@@ -450,6 +450,7 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
     u64 *d_bg = (u64 *)A_(8 * sizeof(u64)), *d_alphas = (u64 *)A_(4 * sizeof(u64)), *d_zeta = (u64 *)A_(8 * sizeof(u64)), *d_pih = (u64 *)A_(4 * sizeof(u64));
     if (!d_proof || !ch || !d_bg || !d_alphas || !d_zeta || !d_pih) return ctx->fail(ZK_ERR_OOM, "prove_plonk: out of device memory");
     ctx->h_stage_used = 0;
+    zk_host_transcript_begin_proof(ctx);
     u64 *h_out = (u64 *)ctx->pinned_out((y.total + 1) * sizeof(u64));
     if (!h_out) return ctx->fail(ZK_ERR_OOM, "prove_plonk: pinned download buffer");
     {
@@ -631,5 +632,6 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
         ctx->fail(rc, "prove_plonk: device-side check failed");
         hipMemsetAsync(ctx->d_err, 0, sizeof(u64), ctx->stream);
     }
+    if (const int32_t he = zk_host_transcript_take_error(ctx)) { if (rc == ZK_OK) { rc = he; ctx->fail(rc, "prove_plonk: host-side transcript check failed"); } }
     return rc;
 }

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void pow_grind_kernel(u64 *pow_state /* 14 wor
 }
 
 int32_t zk_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops) {
+    if (ctx->host_transcript) return zk_host_transcript_run(ctx, c, ops);
     const int wave = (ctx->poseidon_mfma & 4) ? 0 : 1;
     ZK_LAUNCH(ctx, "transcript", transcript_kernel, dim3(1), dim3(64), 0, c, ops, ctx->d_err, wave, ctx->force_redo);
     return ZK_OK;

@@ -90,7 +90,8 @@ class RecursionCircuits:
 class ProverState:
     """Per-process immutable prover state: StarkConfig + one zk_ctx per worker thread (+ the recursion circuits, if supplied)."""
 
-    def __init__(self, device=0, config=None, recursion: Optional[RecursionCircuits] = None, stark_only=False, chain_streams=3, chain_overlap="auto"):
+    def __init__(self, device=0, config=None, recursion: Optional[RecursionCircuits] = None, stark_only=False, chain_streams=3, chain_overlap="auto",
+                 host_transcript=True):
         """stark_only: TxProof.execute stops after the STARK proofs (BASELINE's headline unit) instead of failing for want of
         recursion circuits; never set together with `recursion`.  chain_streams: how many of a transaction's (independent) shrink
         chains one worker proves side by side, each on a context / stream of its own (1: one after another, as upstream's loop; 3 measured
@@ -102,6 +103,8 @@ class ProverState:
         # Measured on one MI355X: alone a transaction takes 77 ms instead of 89, but with 4 / 8 transactions in flight the GPU has no idle
         # issue slots left to hide the chains in and the extra streams cost 10 % (19.4 against 21.7 / 22.6 tx/s).  "auto" (default): overlap
         # while at most `overlap_max_inflight` prove_root calls of this process are running.
+        # host_transcript: in the latency regime (the rule of chain_overlap) the sponge runs on a host thread; False keeps it on the device always
+        self.host_transcript = bool(host_transcript)
         self.chain_overlap = chain_overlap if chain_overlap in (True, False) else "auto"
         self.overlap_max_inflight = 2
         self._active, self._active_lock = 0, threading.Lock()
@@ -161,13 +164,13 @@ P_STATE: Optional[ProverState] = None
 _lock = threading.Lock()
 
 
-def set_prover_state_from_config(device=0, config=None, recursion=None, stark_only=False, chain_streams=3, chain_overlap="auto"):
+def set_prover_state_from_config(device=0, config=None, recursion=None, stark_only=False, chain_streams=3, chain_overlap="auto", host_transcript=True):
     """Initialises the global prover state once; a second call leaves the first state in place and returns it
     (the reference only warns on double initialisation, worker/src/main.rs:25-27)."""
     global P_STATE
     with _lock:
         if P_STATE is None:
-            P_STATE = ProverState(device, config, recursion, stark_only, chain_streams, chain_overlap)
+            P_STATE = ProverState(device, config, recursion, stark_only, chain_streams, chain_overlap, host_transcript)
         return P_STATE
 
 
@@ -218,6 +221,10 @@ def prove_root(input: "GenerationInputs", timing: Optional[dict] = None):
 def _prove_root(st, rc, ctx, input, timing, overlap):
     t0 = time.time()
     ctx.set_side_commit(overlap)          # the same rule for the other latency device: the widest table's trace commitment on a second stream
+    # ... and for the third: the Fiat-Shamir sponge on a host thread (zk_ctx_set_host_transcript: a CPU core permutes in ~3 us, the one-wave
+    # kernel in 7.5; one transaction alone 75 -> 62 ms, with eight in flight no difference), on every context this call proves on
+    host_tr = overlap and st.host_transcript
+    ctx.set_host_transcript(host_tr)
     try:            # by_table[t].by_stark_size[degree_bits]: a size without circuits is an error whatever else happens
         chains = [rc.shrink_chain(ti, t.air, t.log_n) for ti, t in enumerate(input.tables)]
     except KeyError as e:
@@ -227,6 +234,7 @@ def _prove_root(st, rc, ctx, input, timing, overlap):
 
     def shrink(c, ti, t, words, chain):
         """by_table[ti].by_stark_size[log_n].shrink(stark_proof): initial wrapper, then every shrinking wrapper, on context c"""
+        c.set_host_transcript(host_tr)
         state, wires, pubs = rc.initial_wrapper(c, ti, t.air, t.log_n, words)
         proof = zl.prove_plonk(state, wires, pubs, ctx=c)
         if collect is not None:

@@ -55,6 +55,11 @@ int32_t zk_ctx_destroy(zk_ctx *ctx);
  * beside the other tables' commitments (they are independent until their caps are observed, in table order, afterwards).  Same proof.
  * One transaction alone gains a few milliseconds; with the chip saturated by other proofs there is nothing to gain. */
 int32_t zk_ctx_set_side_commit(zk_ctx *ctx, int32_t on);
+/* Latency switch: the Fiat-Shamir sponge of this context's proofs on a host thread instead of the device-resident one-wave kernel (a CPU
+ * core permutes in about a microsecond, the wave in 7.5; SURVEY.md 8a row a8 placed the challenger on the host).  No host synchronisation is
+ * added: observed words reach the host by asynchronous copies, challenges come back behind a stream-side wait.  Same proof words either way.
+ * Call it between proofs.  Environment: ZK_TRANSCRIPT_HOST=1 sets it for every context. */
+int32_t zk_ctx_set_host_transcript(zk_ctx *ctx, int32_t on);
 int32_t zk_ctx_synchronize(zk_ctx *ctx);
 const char *zk_last_error(zk_ctx *ctx);
 /* returns the hipStream_t the ctx enqueues on (for callers that record their own HIP events) */

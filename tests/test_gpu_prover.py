@@ -451,3 +451,38 @@ def test_cfg4_with_prepared_constraint_kernels_bit_exact(zk, orc):
         assert rc == 0 and proof.size == ref.size and (proof == ref).all()
     finally:
         c2.close()
+
+
+def test_host_side_challenger_gives_the_same_proofs(zk, orc):
+    """zk_ctx_set_host_transcript: the duplex sponge on a host thread (observed words by asynchronous D2H copies, challenges back behind a
+    stream-side wait, no host synchronisation of the proving thread) -- the same proof words as the device-resident transcript and as the
+    oracle: a STARK unit with lookups + CTL helpers, a two-table unit, the challenger API itself, and the switch flipped back and forth
+    between proofs of one context."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    c2 = zk.Context(0)
+    try:
+        prog = air.cpu_like_air(21, 5)
+        tr, pub = orc.synth_trace(21, 10, 77)
+        prog2 = air.cpu_like_air(9, 2)
+        tr2, pub2 = orc.synth_trace(9, 8, 78)
+        items = [(prog, 10, tr, pub), (prog2, 8, tr2, pub2)]
+        rc, ref = orc.prove(cfg, items)
+        assert rc == 0
+        dev = zk.prove_tables(c2, cfg, items)
+        assert (dev == ref).all()
+        for rep in range(2):
+            c2.set_host_transcript(True)
+            host = zk.prove_tables(c2, cfg, items)
+            assert host.size == ref.size and (host == ref).all(), "host-side challenger: another proof"
+            # the challenger object of the C ABI on the host path: a long observe (several rate-sized chunks + a ragged tail), squeezes in between
+            ch, och = c2.challenger(), orc.Challenger()
+            xs = np.array([(i * 0x9E3779B97F4A7C15) % 0xFFFFFFFF00000001 for i in range(1, 1 + 8 * 37 + 5)], dtype=np.uint64)
+            ch.observe(xs[:100]); och.observe(xs[:100])
+            assert (ch.get(3) == och.get(3)).all()
+            ch.observe(xs[100:]); och.observe(xs[100:])
+            assert (ch.get(9) == och.get(9)).all() and (ch.compact() == och.compact()).all()
+            c2.set_host_transcript(False)
+            assert (zk.prove_tables(c2, cfg, items) == ref).all()
+    finally:
+        c2.close()
