@@ -334,3 +334,28 @@ int32_t zk_host_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops
     }
     return ZK_OK;
 }
+
+// ---- the host permutation and sponge by themselves (no GPU needed): what the CPU suite pins to upstream's known-answer vectors
+extern "C" int32_t zk_host_poseidon_permute(uint64_t state[12]) {
+    if (!state) return ZK_ERR_INVALID_ARG;
+    u64 s[12];
+    for (int i = 0; i < 12; i++) s[i] = state[i] >= psdh::P ? state[i] - psdh::P : state[i];
+    psdh::permute(s);
+    for (int i = 0; i < 12; i++) state[i] = s[i];
+    return ZK_OK;
+}
+// one pass of the host challenger over a script: ops[i] > 0 = observe that many of the next `elems`, ops[i] < 0 = squeeze -ops[i] challenges
+// into `out`, ops[i] == 0 = compact; returns the number of challenges written (or a negative ZK_ERR_*)
+extern "C" int64_t zk_host_challenger_script(const int32_t *ops, uint32_t n_ops, const uint64_t *elems, size_t n_elems, uint64_t *out, size_t cap_out,
+                                             uint64_t state_out[12]) {
+    if ((!ops && n_ops) || (!elems && n_elems)) return ZK_ERR_INVALID_ARG;
+    psdh::Sponge S;
+    size_t at = 0, w = 0;
+    for (uint32_t i = 0; i < n_ops; i++) {
+        if (ops[i] > 0) { for (int32_t k = 0; k < ops[i]; k++) { if (at >= n_elems) return ZK_ERR_INVALID_ARG; S.observe(elems[at++]); } }
+        else if (ops[i] < 0) { for (int32_t k = 0; k < -ops[i]; k++) { if (w >= cap_out) return ZK_ERR_BUFFER_TOO_SMALL; out[w++] = S.get(); } }
+        else { if (S.n_in) S.duplex(); S.n_out = 0; }
+    }
+    if (state_out) for (int i = 0; i < 12; i++) state_out[i] = S.state[i];
+    return (int64_t)w;
+}

@@ -60,6 +60,12 @@ int32_t zk_ctx_set_side_commit(zk_ctx *ctx, int32_t on);
  * added: observed words reach the host by asynchronous copies, challenges come back behind a stream-side wait.  Same proof words either way.
  * Call it between proofs.  Environment: ZK_TRANSCRIPT_HOST=1 sets it for every context. */
 int32_t zk_ctx_set_host_transcript(zk_ctx *ctx, int32_t on);
+/* The host challenger's permutation and sponge by themselves (pure host code, no context, no GPU): for the CPU test suite, which pins them
+ * to upstream's known-answer vectors.  zk_host_challenger_script runs one pass over a script: ops[i] > 0 observes that many of the next
+ * `elems`, ops[i] < 0 squeezes -ops[i] challenges into `out`, ops[i] == 0 is Challenger::compact; returns the number of challenges written. */
+int32_t zk_host_poseidon_permute(uint64_t state[12]);
+int64_t zk_host_challenger_script(const int32_t *ops, uint32_t n_ops, const uint64_t *elems, size_t n_elems, uint64_t *out, size_t cap_out,
+                                  uint64_t state_out[12]);
 int32_t zk_ctx_synchronize(zk_ctx *ctx);
 const char *zk_last_error(zk_ctx *ctx);
 /* returns the hipStream_t the ctx enqueues on (for callers that record their own HIP events) */

@@ -234,3 +234,49 @@ def test_no_shipped_kernel_uses_scratch():
     assert not bad, "kernels with scratch: %s" % bad
     # two 512-thread workgroups of the NTT pass kernel per compute unit: at most 128 registers
     assert all(k["vgpr"] + k["agpr"] <= 128 for k in ks if "ntt_fast_kernel" in k["name"])
+
+
+def test_host_challenger_permutation_and_sponge_against_upstream_vectors_and_the_oracle(zk):
+    """The host-side challenger (zk_ctx_set_host_transcript) runs its own scalar Poseidon and duplex sponge on CPU threads; both are plain
+    host code and are pinned HERE, without a GPU: the permutation to upstream's four `test_vectors` KATs (tests/golden/vectors.json) and,
+    for random and non-canonical inputs, to the oracle's; the sponge (observe / get / compact in every buffer state) to the oracle's
+    challenger.  (On the GPU box the prover suites then run with the switch on and compare whole proofs.)"""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import orc
+    L = zk.lib()
+    P = 0xFFFFFFFF00000001
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))
+    for kat in gold["poseidon_kats"]:
+        st = np.array([int(x, 16) for x in kat["input"]], dtype=np.uint64)
+        assert L.zk_host_poseidon_permute(st.ctypes.data_as(C.c_void_p)) == 0
+        assert ["%016x" % int(x) for x in st] == kat["output"]
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        st = rng.integers(0, 1 << 63, size=12, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=12, dtype=np.uint64)      # any 64-bit words
+        want = orc.poseidon(st)
+        got = st.copy()
+        assert L.zk_host_poseidon_permute(got.ctypes.data_as(C.c_void_p)) == 0 and (got == want).all()
+    edge = np.array([P, P + 1, (1 << 64) - 1, P - 1, 0, 1, 1 << 32, (1 << 32) - 1, 0xFFFFFFFF, 0xFFFFFFFF00000000, 2, 3], dtype=np.uint64)
+    got = edge.copy(); L.zk_host_poseidon_permute(got.ctypes.data_as(C.c_void_p))
+    assert (got == orc.poseidon(edge)).all()
+    # the sponge: scripts of observes and squeezes hitting every (n_in, n_out) state, against the oracle's challenger
+    L.zk_host_challenger_script.restype = C.c_int64
+    for script in ([3, -2, 8, -1, 13, -9, -3, 1, 16, -84], [8, 8, -8, -1, 0, 5, -1], [1, -1] * 9, [0, -3, 0, 7, 0, -1], [296 + 5, -3, 100, -9]):
+        n_obs = sum(k for k in script if k > 0)
+        xs = rng.integers(0, P, size=max(1, n_obs), dtype=np.uint64)
+        ops = np.array(script, dtype=np.int32)
+        out = np.empty(sum(-k for k in script if k < 0) + 1, dtype=np.uint64)
+        st = np.empty(12, dtype=np.uint64)
+        n = L.zk_host_challenger_script(ops.ctypes.data_as(C.c_void_p), C.c_uint32(ops.size), xs.ctypes.data_as(C.c_void_p), C.c_size_t(n_obs),
+                                        out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), st.ctypes.data_as(C.c_void_p))
+        oc, want, at = orc.Challenger(), [], 0
+        for k in script:
+            if k > 0:
+                oc.observe(xs[at:at + k]); at += k
+            elif k < 0:
+                want += oc.get(-k).tolist()
+            else:
+                oc.compact()
+        assert n == len(want) and out[:n].tolist() == want, script
