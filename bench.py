@@ -648,6 +648,22 @@ def main():
                        "note": "the linear layers run on the i8 matrix cores, the s-boxes and limb recombination on the vector "
                                "ALU; bound = measured chip rate of v_mad_u64_u32 wave-instructions (tools/ubench_int.hip) / VALU "
                                "instructions per 64-permutation wave (SQ_INSTS_VALU)"}
+            if alu is not None:
+                # what the chip gave this kernel when it was last counted (tools/pmc_round4.sh, committed summary): the clock (GRBM_GUI_ACTIVE / 8 /
+                # duration) and the share of SIMD cycles that issued an instruction (SQ_ACTIVE_INST_ANY x 4 quad-cycles / 1024 SIMDs / kernel cycles)
+                try:
+                    pf = newest_profile("r*_pmc_bench_regions_and_ntt_summary.json")
+                    pj = json.load(open(pf))
+                    kn = "hash_leaves_colmajor_mfma_kernel"
+                    ghz = pj["derived"]["effective_clock_GHz"][kn]["GHz"]
+                    act = [v[kn]["mean"] for t in pj["counters"].values() for c, v in t.items() if c == "SQ_ACTIVE_INST_ANY" and kn in v][0]
+                    gui = [v[kn]["mean"] for t in pj["counters"].values() for c, v in t.items() if c == "GRBM_GUI_ACTIVE" and kn in v][0]
+                    alu["clock_GHz_under_this_kernel"] = round(ghz, 3)
+                    alu["simd_issue_busy_fraction"] = round(act * 4.0 / 1024.0 / (gui / 8.0), 3)
+                    alu["frac_of_valu_issue_bound_at_that_clock"] = round(alu["frac_of_valu_issue_bound"] * 2.4 / ghz, 3)
+                    alu["sources"].append(os.path.basename(pf))
+                except Exception as e:
+                    alu["clock_note"] = "no committed counter summary: %s" % str(e)[:80]
             line["roofline"] = {
                 "bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src if dcols is not None else None, "alu": alu,
