@@ -15,6 +15,7 @@
 // published -- a stream never waits for a value that will not come -- and the error reaches the proof's status word.
 #include <stdlib.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -159,6 +160,7 @@ void process(zk_host_transcript *H, HostJob &job) {
 }
 
 void Service::run() {
+    u32 idle = 0;
     for (;;) {
         zk_host_transcript *H = nullptr;
         HostJob job;
@@ -178,7 +180,15 @@ void Service::run() {
                 break;
             }
         }
-        if (!H) { for (int i = 0; i < 32; i++) _mm_pause(); continue; }
+        if (!H) {
+            // nothing ready: the jobs in the queues wait for words the GPU has not produced yet.  Spin for most of a millisecond (a
+            // transcript phase answers within microseconds; napping after 100 us cost the seven-table unit 1.3 of 31 ms), then nap:
+            // during a proof's long kernels nobody is waiting for this thread
+            if (++idle < 512) { for (int i = 0; i < 32; i++) _mm_pause(); }
+            else std::this_thread::sleep_for(std::chrono::microseconds(30));
+            continue;
+        }
+        idle = 0;
         std::atomic_thread_fence(std::memory_order_acquire);
         process(H, job);
         std::atomic_thread_fence(std::memory_order_release);
