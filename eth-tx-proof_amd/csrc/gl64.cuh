@@ -386,3 +386,16 @@ GLD u32 bitrev_u32(u32 x, u32 bits) {
     return r;
 #endif
 }
+
+// Launch index -> 256-point block of a compiled constraint kernel (prover_quotient_jit.hip).  In leaf (bit-reversed) order the `next` row
+// of every point of block b lies in exactly one other block, the one whose bit-reversed block number is 2^rate_bits higher: blocks form a
+// cycle, and in the plain order b = blockIdx a block's `next` rows are a quarter of the array away -- a second full read of the LDE
+// (FETCH 1.7 x the local rows).  Here the launch walks the cycle: workgroups go to the eight XCDs round robin, so
+// XCD x (launch indices x, x + 8, ..) gets a contiguous arc of the cycle, and what block k reads as `next` is what its neighbour on the
+// same XCD (its L2) reads as `local` at about the same time.  A bijection on [0, 2^(lgL - 8)); needs lgL - 8 >= 3 + rate_bits.
+GLD u32 zk_qblock(u32 j, u32 lgL, u32 rate_bits) {
+    const u32 nbits = lgL - 8, nb = 1u << nbits;
+    const u32 pos = (j & 7u) * (nb >> 3) + (j >> 3);
+    const u32 c = ((pos << rate_bits) | (pos >> (nbits - rate_bits))) & (nb - 1);
+    return bitrev_u32(c, nbits);
+}

@@ -223,6 +223,9 @@ int32_t zk_quotient_dev(zk_ctx *ctx, const DevAir &air, const zk_stark_config &c
         jp.trace_lde = p.trace_lde; jp.aux_lde = p.aux_lde; jp.pub = p.pub; jp.chal = p.chal; jp.alphas = p.alphas; jp.lag = p.lag;
         jp.xA = p.xA; jp.xB = p.xB; jp.out = p.out; jp.L = L; jp.last_inv = p.last_inv; jp.lgL = lgL;
         jp.state = nullptr; jp.redo_cap = 0; jp.force = ctx->force_redo ? 1u : 0u;
+        // blocks walk the cycle of `next` rows, one arc per XCD (zk_qblock, gl64.cuh); ZK_QUOTIENT_REMAP=0: plain order (A/B switch)
+        static const int remap = getenv("ZK_QUOTIENT_REMAP") ? atoi(getenv("ZK_QUOTIENT_REMAP")) : 1;
+        jp.pad = (remap && lgL >= 8 + 3 + rate_bits && (L & 2047) == 0) ? 1u : 0u;
         for (int i = 0; i < 8; i++) jp.zh_inv[i] = p.zh_inv[i];
         rc = zk_quotient_jit_launch(ctx, air.host, p.C, p.A, nch, rate_bits, jp);
         if (rc == ZK_OK) done = true;

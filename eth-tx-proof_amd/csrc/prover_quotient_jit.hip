@@ -170,7 +170,7 @@ static std::string generate_segmented(const zk_air *air, u32 C, u32 A, u32 nch, 
             emit_instr(g, air->instrs[pc], nch);
         }
         appendf(s, "// instructions [%u, %u)\nextern \"C\" __global__ __launch_bounds__(256) void %s_%u(QJitParams p) {\n", pl.cut[k], pl.cut[k + 1], kname, k);
-        s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
+        appendf(s, "    const u64 s = (u64)(p.pad ? zk_qblock(blockIdx.x, p.lgL, %uu) : blockIdx.x) * 256 + threadIdx.x;\n    if (s >= p.L) return;\n", rate_bits);
         s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
         appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
         appendf(s, "    const u64 *sin = p.state + %s + s; u64 *sout = p.state + %s + s;\n", (k & 1) ? std::string("(u64)" + std::to_string(NS) + " * p.L").c_str() : "0",
@@ -219,7 +219,7 @@ std::string generate(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, co
     std::string s;
     if (standalone) { s += "#include \"gl64.cuh\"\n"; s += QJIT_PARAMS_SRC; }
     appendf(s, "extern \"C\" __global__ __launch_bounds__(256) void %s(QJitParams p) {\n", kname);
-    s += "    const u64 s = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (s >= p.L) return;\n";
+    appendf(s, "    const u64 s = (u64)(p.pad ? zk_qblock(blockIdx.x, p.lgL, %uu) : blockIdx.x) * 256 + threadIdx.x;\n    if (s >= p.L) return;\n", rate_bits);
     s += "    const u32 i = bitrev_u32((u32)s, p.lgL);\n";
     appendf(s, "    const u64 sn = bitrev_u32((i + %uu) & (u32)(p.L - 1), p.lgL);\n", 1u << rate_bits);
     // The whole evaluation is one generic lambda instantiated twice: with glx<false> (products without the two 1-in-2^32 repairs,
@@ -639,7 +639,7 @@ static int32_t jit_compile_cached(zk_ctx *ctx, const std::string &base_key, bool
     if (!may_compile) { k = JitKernel(); return ZK_OK; }
     std::string disk_key = base_key;
     {
-        const u64 ver[2] = {6 /* generator version */, fnv1a(GL64_SRC)};
+        const u64 ver[2] = {7 /* generator version */, fnv1a(GL64_SRC)};
         disk_key.append((const char *)ver, sizeof ver);
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) disk_key.append(pr.gcnArchName);
