@@ -291,7 +291,17 @@ static const PsdmTables *psdm_tables(zk_ctx *ctx) {
     ctx->d_psdm = dev_tab[ctx->device];
     return (const PsdmTables *)ctx->d_psdm;
 }
-#define PSDM_MIN_UNITS 16384    // below this a launch no longer fills the chip two waves per SIMD deep: keep thread-per-unit
+// From how many units (leaves, parents) a launch goes to the matrix-core kernels (32 per wave below 65 536).  Rounds 2-3 drew the line at
+// 16 384 ("below this a launch no longer fills the chip two waves per SIMD deep") and gave smaller launches to the lane-cooperative /
+// wave-wide kernels, which answer sooner but cost 6-22 x the vector instructions per permutation (16 lanes: 1 525, a wave: 3 000, against
+// 134-268).  Round 4 counted a transaction's instructions (tools/pmc_prove_root_valu.sh: those kernels were 20 % of them) and moved the
+// line to 2 048: +5 % transactions/s with eight in flight, and a transaction ALONE is no slower (62.6 against 63.5 ms) -- between 2 048 and
+// 16 384 units the cooperative kernels' extra instructions cost as much time as their parallelism saves.  ZK_PSDM_MIN_UNITS overrides.
+static size_t psdm_min_units() {
+    static const size_t v = getenv("ZK_PSDM_MIN_UNITS") ? (size_t)atol(getenv("ZK_PSDM_MIN_UNITS")) : 2048;
+    return v < 256 ? 256 : v;
+}
+#define PSDM_MIN_UNITS psdm_min_units()
 
 template <bool EXACT> __device__ __forceinline__ u64 leaf_sponge_rowmajor(const u64 *__restrict__ p, u32 leaf_len, int canon, u64 s[12]) {
     psd::core<EXACT> pc; pc.fl = 0;
