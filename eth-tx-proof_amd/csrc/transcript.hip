@@ -146,14 +146,17 @@ int32_t zk_pow_search_dev(zk_ctx *ctx, u32 min_zeros, u64 *d_pow_state) {
     // expected 2^min_zeros candidates; 2^(min_zeros+6) of them fail with probability e^-64.  Later blocks exit early
     // once a smaller witness is recorded.
     u64 total = (u64)1 << (min_zeros + 6 > 40 ? 40 : min_zeros + 6);
-    // Launches grow: the first covers the expected search (2^min_zeros candidates: one wave per SIMD at 16 bits, i.e. ONE permutation's
-    // latency; misses with probability 1/e), the next 4 x, the last the rest.  A later launch costs its blocks one load each once a
-    // witness is known.  (Round 2 started with 4 x the expected search: every proof paid 2^18 permutations, 160 us, where 2^16 + 0.37 x
-    // 2^18 are enough on average; before that, 32 equal launches were 2 ms of launch latency per seven-table unit.)
+    // Launches double: the first covers the expected search (2^min_zeros candidates: one wave per SIMD at 16 bits, i.e. ONE permutation's
+    // latency; misses with probability 1/e), every further one as many candidates as all before it (cumulative 2, 4, 8 x: missed with
+    // probability e^-2, e^-4, e^-8), the last the rest.  A later launch costs its blocks one load each once a witness is known.  Expected
+    // work 1.7 x the expected search; round 3's 1 x / 4 x / rest was 3.2 x -- every second proof ran 2^18 permutations where 2^17 do, and
+    // the PoW search was 5.5 % of a transaction's vector instructions (profiles/r04l_...); round 2's 4 x first was 2^18 for every proof,
+    // and before that 32 equal launches were 2 ms of launch latency per seven-table unit.
     u64 base = 0;
-    const u64 first = (u64)1 << min_zeros, second = (u64)1 << (min_zeros + 2);
-    const u64 cuts[3] = {first < total ? first : total, second < total ? second : total, total};
-    for (int k = 0; k < 3; k++) {
+    u64 cuts[5];
+    for (int k = 0; k < 4; k++) { const u64 c = (u64)1 << (min_zeros + k); cuts[k] = c < total ? c : total; }
+    cuts[4] = total;
+    for (int k = 0; k < 5; k++) {
         if (cuts[k] <= base) continue;
         u64 cnt = cuts[k] - base;
         while (cnt) {                                            // a launch is at most 2^31 - 256 blocks
