@@ -182,6 +182,15 @@ void zk_ctx::wait_upload(const void *d_ptr) {
     }
 }
 
+hipError_t zk_ctx::wait_stream() {
+    static const int blocking = getenv("ZK_BLOCKING_SYNC") ? atoi(getenv("ZK_BLOCKING_SYNC")) : 0;
+    if (!blocking) return hipStreamSynchronize(stream);
+    if (!sync_event && hipEventCreateWithFlags(&sync_event, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { sync_event = nullptr; return hipStreamSynchronize(stream); }
+    hipError_t e = hipEventRecord(sync_event, stream);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(sync_event);
+}
+
 void zk_ctx::release(void *p) {
     if (!p) return;
     auto it = block_size.find(p);
@@ -299,6 +308,7 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_out) hipHostFree(c->h_out);
     if (c->h_io) hipHostFree(c->h_io);
+    if (c->sync_event) hipEventDestroy(c->sync_event);
     if (c->h_packed_off) hipHostFree(c->h_packed_off);
     if (c->packed_off_done) hipEventDestroy(c->packed_off_done);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }

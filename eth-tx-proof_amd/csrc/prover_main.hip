@@ -369,7 +369,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
         if (hipMemcpyAsync(h_out, d_proof, total * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
         if (hipMemcpyAsync(h_out + total, ctx->d_err, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
     }
-    hipError_t se = hipStreamSynchronize(ctx->stream);
+    hipError_t se = ctx->wait_stream();
     if (se != hipSuccess && rc == ZK_OK) rc = ctx->fail(ZK_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
     if (rc == ZK_OK) { memcpy(proof_out, h_out, total * sizeof(u64)); err_word = h_out[total]; }
     if (rc == ZK_OK && err_word) {

@@ -624,7 +624,7 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
     u64 err_word = 0;
     if (hipMemcpyAsync(h_out, d_proof, y.total * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
     if (hipMemcpyAsync(h_out + y.total, ctx->d_err, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
-    hipError_t se = hipStreamSynchronize(ctx->stream);
+    hipError_t se = ctx->wait_stream();
     if (se != hipSuccess && rc == ZK_OK) rc = ctx->fail(ZK_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
     if (rc == ZK_OK) { memcpy(proof_out, h_out, y.total * sizeof(u64)); err_word = h_out[y.total]; }
     if (rc == ZK_OK && err_word) {

@@ -104,7 +104,9 @@ class ProverState:
         # issue slots left to hide the chains in and the extra streams cost 10 % (19.4 against 21.7 / 22.6 tx/s).  "auto" (default): overlap
         # while at most `overlap_max_inflight` prove_root calls of this process are running.
         # host_transcript: in the latency regime (the rule of chain_overlap) the sponge runs on a host thread; False keeps it on the device always
-        self.host_transcript = bool(host_transcript)
+        # ("always" -- also what ZK_TRANSCRIPT_HOST=1 in the environment means here -- keeps it on the host in every regime)
+        import os as _os
+        self.host_transcript = "always" if (host_transcript == "always" or _os.environ.get("ZK_TRANSCRIPT_HOST", "0") not in ("", "0")) else bool(host_transcript)
         self.chain_overlap = chain_overlap if chain_overlap in (True, False) else "auto"
         self.overlap_max_inflight = 2
         self._active, self._active_lock = 0, threading.Lock()
@@ -223,7 +225,7 @@ def _prove_root(st, rc, ctx, input, timing, overlap):
     ctx.set_side_commit(overlap)          # the same rule for the other latency device: the widest table's trace commitment on a second stream
     # ... and for the third: the Fiat-Shamir sponge on a host thread (zk_ctx_set_host_transcript: a CPU core permutes in ~3 us, the one-wave
     # kernel in 7.5; one transaction alone 75 -> 62 ms, with eight in flight no difference), on every context this call proves on
-    host_tr = overlap and st.host_transcript
+    host_tr = (overlap and st.host_transcript) or st.host_transcript == "always"
     ctx.set_host_transcript(host_tr)
     try:            # by_table[t].by_stark_size[degree_bits]: a size without circuits is an error whatever else happens
         chains = [rc.shrink_chain(ti, t.air, t.log_n) for ti, t in enumerate(input.tables)]
