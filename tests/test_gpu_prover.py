@@ -484,5 +484,14 @@ def test_host_side_challenger_gives_the_same_proofs(zk, orc):
             assert (ch.get(9) == och.get(9)).all() and (ch.compact() == och.compact()).all()
             c2.set_host_transcript(False)
             assert (zk.prove_tables(c2, cfg, items) == ref).all()
+        # more observed words than the 16 MiB pinned ring of the mailbox holds (2.2 M words in 4 096-word calls): the ring is drained and
+        # started over in the middle of the stream of jobs, the sponge must not notice
+        c2.set_host_transcript(True)
+        rng = np.random.default_rng(4)
+        big = rng.integers(0, 0xFFFFFFFF00000001, size=(1 << 21) + (1 << 17) + 3, dtype=np.uint64)
+        ch, och = c2.challenger(), orc.Challenger()
+        ch.observe(big); och.observe(big)
+        assert (ch.get(5) == och.get(5)).all() and (ch.compact() == och.compact()).all()
+        c2.set_host_transcript(False)
     finally:
         c2.close()
