@@ -385,9 +385,9 @@ extern "C" int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const
     if (rc == ZK_OK) rc = zk_batch_commit_dev(ctx, d_cols, c->degree_bits, NC + R, cfg->rate_bits, cfg->cap_height, 1, &st->cs);
     if (rc == ZK_OK) {
         // CircuitBuilder::build: circuit digest = hash_no_pad(constants_sigmas_cap | hash_pad(domain_separator) | degree_bits);
-        // hash_pad(x) = hash_no_pad(x | 1 | 0.. | 1), padded to a multiple of the rate: [1,0,0,0,0,0,0,1] for the empty separator
+        // hash_pad(x) = hash_no_pad(x | 1 | 0.. | 1), padded to a multiple of ZK_HASH_PAD_MULTIPLE (zkgl.h: the rate): [1,0,0,0,0,0,0,1] for the empty separator
         u32 nd = c->n_domain_separator, np = nd + 1;
-        while ((np + 1) % 8) np++;
+        while ((np + 1) % ZK_HASH_PAD_MULTIPLE) np++;
         np++;
         u64 *d_in = (u64 *)own.get((size_t)(capw + 5) * sizeof(u64)), *d_pad = (u64 *)own.get((size_t)np * sizeof(u64));
         if (!d_in || !d_pad) rc = ZK_ERR_OOM;

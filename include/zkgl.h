@@ -449,6 +449,11 @@ typedef struct zk_plonk_state zk_plonk_state;   /* prover data of one circuit: c
 /* CircuitBuilder::build's prover-side part: commit constants | sigmas (rate_bits, cap_height of cfg), derive the circuit digest
  * = hash_no_pad(constants_sigmas_cap | hash_pad(domain_separator) | degree_bits); hash_pad = pad10*1 to a multiple of the rate,
  * so the empty separator hashes [1,0,0,0,0,0,0,1].  cfg: zk_stark_config with the recursion parameters (rate_bits 3, 28 query rounds ..). */
+/* Hasher::hash_pad (the domain separator inside the circuit digest) pads  x | 1 | 0.. | 1  to a multiple of this many words.  plonky2 0.2.2 is
+ * not in the reference tree; RATE (8) is what both this library and the oracle restate, from recall -- WIDTH (12) would be the other reading.
+ * One constant here, one in oracle/oracle.h (ORC_HASH_PAD_MULTIPLE), one in oracle/pyspec.py (HASH_PAD_MULTIPLE): a maintainer with the crate
+ * at hand settles it in three lines. */
+#define ZK_HASH_PAD_MULTIPLE 8u
 int32_t zk_plonk_setup(zk_ctx *ctx, const zk_stark_config *cfg, const zk_plonk_circuit *circuit, zk_plonk_state **out);
 int32_t zk_plonk_state_free(zk_plonk_state *st);
 int32_t zk_plonk_circuit_digest(zk_plonk_state *st, uint64_t digest_out[4]);

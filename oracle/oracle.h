@@ -20,6 +20,9 @@
 #include <stddef.h>
 #include "../include/zkgl.h" /* shared plain-data structs only: zk_air, zk_instr, zk_stark_config */
 
+/* Hasher::hash_pad pads to a multiple of this many words: RATE (8), restated from recall; see ZK_HASH_PAD_MULTIPLE in include/zkgl.h */
+#define ORC_HASH_PAD_MULTIPLE 8u
+
 #ifdef __cplusplus
 extern "C" {
 #endif

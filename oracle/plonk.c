@@ -137,7 +137,7 @@ orc_plonk_state *orc_plonk_setup(const zk_stark_config *cfg, const zk_plonk_circ
     memcpy(in, orc_batch_cap(st->cs), capw * sizeof(uint64_t));
     {
         uint32_t nd = c->n_domain_separator, np = nd + 1;
-        while ((np + 1) % 8) np++;
+        while ((np + 1) % ORC_HASH_PAD_MULTIPLE) np++;
         np++;
         uint64_t *pad = (uint64_t *)calloc(np, sizeof(uint64_t));
         for (uint32_t i = 0; i < nd; i++) pad[i] = gl_canon(c->domain_separator[i]);

@@ -622,10 +622,13 @@ def _fri_prove(cfg, k, oracles, batches, ch):
 
 
 # ------------------------------------------------------------------------------------------------ Plonk prover (second restatement)
+HASH_PAD_MULTIPLE = 8      # RATE, restated from recall (WIDTH = 12 would be the other reading): include/zkgl.h ZK_HASH_PAD_MULTIPLE
+
+
 def hash_pad(x):
-    """Hasher::hash_pad: x | 1 | 0.. | 1, padded to a multiple of the rate, through hash_no_pad (pad10*1)"""
+    """Hasher::hash_pad: x | 1 | 0.. | 1, padded to a multiple of HASH_PAD_MULTIPLE, through hash_no_pad (pad10*1)"""
     p = [v % P for v in x] + [1]
-    while (len(p) + 1) % 8:
+    while (len(p) + 1) % HASH_PAD_MULTIPLE:
         p.append(0)
     p.append(1)
     return hash_no_pad(p)
