@@ -118,3 +118,64 @@ def test_whole_prove_root_of_configs3_hashes_to_the_oracles_digests(ent, overlap
         if ops.P_STATE is not None:
             ops.P_STATE.drop_ctx()
         ops.P_STATE = old
+
+
+# ---- BASELINE configs[4] at full size on one card: a 16-transaction block, map -> fold -> block (round 4)
+_BLOCK_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proof_digests_block.json")
+
+
+@pytest.mark.skipif(not os.path.exists(_BLOCK_GOLD), reason="tests/golden/proof_digests_block.json not generated (tools/gen_golden_block.py)")
+def test_sixteen_transaction_block_hashes_to_the_oracles_digests():
+    """The caller of the operators at full size (/root/reference/leader/src/prover.rs:20-43, BASELINE configs[4] on one GPU): 16 transactions --
+    each the seven tables of configs[3], shrink chains and root proof -- mapped over four workers, the leader's balanced pairwise fold
+    (15 aggregation proofs of 2^14 rows), the block proof.  Every root proof, every proof of every fold level and the block proof hash to the
+    ORACLE's digests (tools/gen_golden_block.py: four distinct transactions, each used four times)."""
+    from eth_tx_proof_amd import leader, ops, plonk
+    gold = json.load(open(_BLOCK_GOLD))
+    old = ops.P_STATE
+    ops.P_STATE = None
+    try:
+        rec = plonk.SyntheticRecursion()
+        st = ops.set_prover_state_from_config(0, recursion=rec)
+        state_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eth-tx-proof_amd", "prover_state")
+        c0 = st.ctx()
+        units = []
+        for u in range(gold["units"]):
+            tabs = []
+            for t, (w, lg) in enumerate(zip(gold["widths"], gold["log_sizes"])):
+                d, pub = zl.synth_trace_dev(c0, w, lg, gold["block_seed"] + 100000 * (u % gold["distinct"]) + 1000 * t)
+                tabs.append(ops.TableInput(air.cpu_like_air(w, min(19, w // 4)), lg, d, pub))
+            units.append(ops.GenerationInputs(tabs, txn_number_before=u, block_number=1))
+        c0.synchronize()
+        if os.path.isdir(state_dir):
+            zl.prover_state_cache_dir(state_dir)
+            try:
+                st.prepare(units[0].tables)
+            finally:
+                zl.prover_state_cache_dir(None)
+        rt = leader.Runtime(num_workers=4)
+        txs = rt.map(ops.TxProof(), units)
+        for u, tx in enumerate(txs):
+            g = gold["roots"][u % gold["distinct"]]
+            assert tx.proof.size == g["words"] and _sha(tx.proof) == g["sha256"], "root proof of transaction %d differs from the oracle's" % u
+        made = []
+
+        class Collect(ops.AggProof):
+            def combine(self, a, b):
+                r = super().combine(a, b)
+                made.append(r.proof)
+                return r
+        agg = leader.Runtime.fold(Collect(), txs)
+        want = [e for lvl in gold["fold_levels"] for e in lvl]
+        assert len(made) == len(want) == gold["units"] - 1
+        for k, (p, g) in enumerate(zip(made, want)):
+            assert p.size == g["words"] and _sha(p) == g["sha256"], "aggregation proof %d differs from the oracle's" % k
+        block = ops.BlockProof().execute(agg)
+        assert block.b_height == 1 and block.intern.size == gold["block"]["words"] and _sha(block.intern) == gold["block"]["sha256"]
+        # the leader's own entry point does the same three stages
+        again = leader.ProverInput(units).prove(leader.Runtime(num_workers=4))
+        assert _sha(again.intern) == gold["block"]["sha256"]
+    finally:
+        if ops.P_STATE is not None:
+            ops.P_STATE.drop_ctx()
+        ops.P_STATE = old
