@@ -151,6 +151,11 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
         go.wait()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if os.environ.get("ZK_VA_PROBE"):          # debug: the runtime's view of the address windows the unexplained GPU faults named, with every context alive and busy
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import va_probe
+            time.sleep(0.2)
+            va_probe.probe("transactions in flight")
         done.wait()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -189,6 +194,46 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
         if ops.P_STATE is not None:
             ops.P_STATE.drop_ctx()
         ops.P_STATE = old
+
+
+def prove_root_record(args, timeout_s=300):
+    """The default line's transaction record, measured by a CHILD process (`bench.py --workload prove_root --inflight 8 --steps 4`) after this
+    process has finished and released its own GPU work: the headline cannot be lost to anything that happens in the transaction workload
+    (rounds 3 and 4 saw one "Memory access fault by GPU" in about twenty runs of it, DESIGN.md section 9, and a faulting process does not
+    exit by itself on this stack).  The child's stderr is passed on (the library's flight recorder writes there)."""
+    import tempfile
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "prove_root", "--inflight", "8", "--steps", "4", "--warmup", "1", "--prepare", args.prepare]
+    with tempfile.TemporaryFile() as err:
+        t0 = time.perf_counter()
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=err, env=dict(os.environ, ZK_BENCH_CHILD="1"))
+        try:
+            out, _ = proc.communicate(timeout=timeout_s)
+            timed_out = False
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            try:
+                out, _ = proc.communicate(timeout=15)
+            except subprocess.TimeoutExpired:
+                out = b""                                  # not reaped: left behind, the line must still go out
+            timed_out = True
+        err.seek(0)
+        etxt = err.read().decode(errors="replace")
+    if etxt:
+        sys.stderr.write(etxt if len(etxt) < 200000 else etxt[:100000] + "\n[...]\n" + etxt[-100000:])
+        sys.stderr.flush()
+    fault = "Memory access fault" in etxt or "[zk-fault]" in etxt
+    if timed_out or proc.returncode != 0:
+        return {"error": ("timed out after %d s" % timeout_s) if timed_out else "child process exited with code %s" % proc.returncode, "gpu_memory_fault": fault,
+                "wall_s": round(time.perf_counter() - t0, 1), "command": " ".join(cmd[1:]), "note": "the child's stderr is in this run's stderr"}
+    try:
+        pr = json.loads(out.decode().strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": "no JSON line from the child process: %s" % str(e)[:200], "gpu_memory_fault": fault}
+    rec = {k: pr[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "one_tx_alone_ms", "timed_proof_check")}
+    rec["config"] = pr["config"]
+    rec["note"] = ("NOT the headline (`value` above is BASELINE's unit metric); measured by a child process after the headline's own work "
+                   "(python bench.py --workload prove_root gives the long form)")
+    return rec
 
 
 def bench_prove_root(args):
@@ -725,13 +770,7 @@ def main():
         # steps (two steps are mostly ramp: 19 against 26 tx/s), one transaction alone split into its three stages, root proof and AllProof
         # against the oracle's committed digests
         if world == 1 and args.log_n == 20 and not args.no_prove_root:
-            try:
-                pr = run_prove_root(8, 4, 1, prepare=args.prepare)
-                line["prove_root"] = {k: pr[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "one_tx_alone_ms", "timed_proof_check")}
-                line["prove_root"]["config"] = pr["config"]
-                line["prove_root"]["note"] = "NOT the headline (`value` above is BASELINE's unit metric); python bench.py --workload prove_root gives the long form"
-            except Exception as e:
-                line["prove_root"] = {"error": str(e)[:300]}
+            line["prove_root"] = prove_root_record(args)
         print(json.dumps(line))
         if isinstance(line.get("prove_root"), dict) and (line["prove_root"].get("timed_proof_check") or {}).get("identical_to_oracle") is False:
             sys.exit("bench.py: the transaction's proofs differ from the oracle's committed digests")

@@ -38,7 +38,7 @@ void *zk_ctx::alloc(size_t bytes) {
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         // give cached blocks back to the driver and retry once
-        for (auto &kv : free_blocks) { hipFree(kv.second); block_size.erase(kv.second); bytes_allocated -= kv.first; }
+        for (auto &kv : free_blocks) { ZK_ALLOC_TRACE("free-dev-oom", kv.second, kv.first); hipFree(kv.second); block_size.erase(kv.second); bytes_allocated -= kv.first; }
         free_blocks.clear();
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) { last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return nullptr; }
@@ -46,13 +46,14 @@ void *zk_ctx::alloc(size_t bytes) {
     block_size[p] = bytes;
     bytes_allocated += bytes;
     if (sync_launch) fprintf(stderr, "[zk] hipMalloc %zu at %p .. %p\n", bytes, p, (void *)((char *)p + bytes));
+    ZK_ALLOC_TRACE("dev-block", p, bytes);
     return p;
 }
 
 const void *zk_ctx::stage_pinned(const void *src, size_t bytes) {
     if (!h_stage) {
         if (hipHostMalloc((void **)&h_stage, (size_t)1 << 20, hipHostMallocDefault) != hipSuccess) { h_stage = nullptr; return nullptr; }
-        h_stage_cap = (size_t)1 << 20; h_stage_used = 0;
+        h_stage_cap = (size_t)1 << 20; h_stage_used = 0; ZK_ALLOC_TRACE("host-stage", h_stage, h_stage_cap);
     }
     size_t need = (bytes + 63) & ~(size_t)63;
     if (h_stage_used + need > h_stage_cap) return nullptr;
@@ -63,10 +64,10 @@ const void *zk_ctx::stage_pinned(const void *src, size_t bytes) {
 }
 void *zk_ctx::pinned_out(size_t bytes) {
     if (h_out_cap >= bytes) return h_out;
-    if (h_out) { hipStreamSynchronize(stream); hipHostFree(h_out); h_out = nullptr; h_out_cap = 0; }
+    if (h_out) { hipStreamSynchronize(stream); ZK_ALLOC_TRACE("free-host-out", h_out, h_out_cap); hipHostFree(h_out); h_out = nullptr; h_out_cap = 0; }
     size_t cap = (bytes + ((size_t)1 << 16)) & ~(((size_t)1 << 16) - 1);
     if (hipHostMalloc((void **)&h_out, cap, hipHostMallocDefault) != hipSuccess) { h_out = nullptr; return nullptr; }
-    h_out_cap = cap;
+    h_out_cap = cap; ZK_ALLOC_TRACE("host-out", h_out, cap);
     return h_out;
 }
 int32_t zk_ctx::upload_small(void *d_dst, const void *src, size_t bytes) {
@@ -88,6 +89,7 @@ int32_t zk_ctx::upload_small(void *d_dst, const void *src, size_t bytes) {
 static bool io_buffer(zk_ctx *c) {
     if (c->h_io) return true;
     if (hipHostMalloc((void **)&c->h_io, ZK_IO_BYTES, hipHostMallocDefault) != hipSuccess) { c->h_io = nullptr; (void)hipGetLastError(); return false; }
+    ZK_ALLOC_TRACE("host-io", c->h_io, ZK_IO_BYTES);
     return true;
 }
 int32_t zk_ctx::copy_h2d_sync(void *d_dst, const void *src, size_t bytes) {
@@ -274,7 +276,9 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
         c->own_stream = true;
     }
     if (hipMalloc((void **)&c->d_err, 256) != hipSuccess) { delete c; return ZK_ERR_OOM; }
+    ZK_ALLOC_TRACE("dev-err-word", c->d_err, 256);
     hipMemsetAsync(c->d_err, 0, 256, c->stream);
+    zk_fault_register_ctx(c);
     *out = c;
     return ZK_OK;
 }
@@ -299,15 +303,17 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     if (!c) return ZK_ERR_INVALID_ARG;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    zk_fault_unregister_ctx(c);
     zk_host_transcript_destroy(c);
     if (c->side) { zk_ctx_destroy(c->side); c->side = nullptr; }
     c->prof_flush();
     for (auto e : c->event_pool) hipEventDestroy(e);
-    if (!c->efence) for (auto &kv : c->block_size) hipFree(kv.first);
-    hipFree(c->d_err);
-    if (c->h_stage) hipHostFree(c->h_stage);
-    if (c->h_out) hipHostFree(c->h_out);
-    if (c->h_io) hipHostFree(c->h_io);
+    ZK_ALLOC_TRACE("ctx-destroy", c, c->block_size.size());
+    if (!c->efence) for (auto &kv : c->block_size) { ZK_ALLOC_TRACE("free-dev-block", kv.first, kv.second); hipFree(kv.first); }
+    ZK_ALLOC_TRACE("free-dev-err-word", c->d_err, 256); hipFree(c->d_err);
+    if (c->h_stage) { ZK_ALLOC_TRACE("free-host-stage", c->h_stage, 0); hipHostFree(c->h_stage); }
+    if (c->h_out) { ZK_ALLOC_TRACE("free-host-out", c->h_out, c->h_out_cap); hipHostFree(c->h_out); }
+    if (c->h_io) { ZK_ALLOC_TRACE("free-host-io", c->h_io, 0); hipHostFree(c->h_io); }
     if (c->sync_event) hipEventDestroy(c->sync_event);
     if (c->h_packed_off) hipHostFree(c->h_packed_off);
     if (c->packed_off_done) hipEventDestroy(c->packed_off_done);
@@ -382,10 +388,12 @@ int32_t zk_host_alloc(zk_ctx *c, size_t bytes, void **h_ptr) {
     hipSetDevice(c->device);
     *h_ptr = nullptr;
     if (hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *h_ptr = nullptr; return c->fail(ZK_ERR_OOM, "zk_host_alloc: hipHostMalloc"); }
+    ZK_ALLOC_TRACE("host-caller", *h_ptr, bytes);
     return ZK_OK;
 }
 int32_t zk_host_free(zk_ctx *c, void *h_ptr) {
     if (!c) return ZK_ERR_INVALID_ARG;
+    ZK_ALLOC_TRACE("free-host-caller", h_ptr, 0);
     if (h_ptr && hipHostFree(h_ptr) != hipSuccess) return c->fail(ZK_ERR_HIP, "zk_host_free");
     return ZK_OK;
 }

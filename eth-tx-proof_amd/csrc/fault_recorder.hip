@@ -1,0 +1,164 @@
+// Flight recorder for "Memory access fault by GPU".  Host code only.
+//
+// Rounds 3 and 4 each ended with one unexplained GPU memory fault in about twenty runs of the transaction workload:
+// the runtime prints one address, aborts, and nothing says which kernel, which buffer, or whether the address was ever valid.  This file
+// keeps, at the cost of a few stores per launch / allocation,
+//   * the last launches of every context (name, grid, time),
+//   * every block the library took from or gave back to the driver (device blocks, pinned host buffers), alive or released,
+// and registers a system-event handler with the HSA runtime (hsa_amd_register_system_event_handler).  When a fault event arrives the handler
+// writes to stderr: the address and reason bits; what the RUNTIME knows about the address and about the same address 4 GiB higher and lower
+// (hsa_amd_pointer_info covers every allocation of the process, the HIP runtime's own included); the nearest live allocation below the
+// address and the distance to its end (an overrun reads as a few bytes to a few KB past an end; a stale pointer does not); the library's own
+// records that contain the address; the last launches of every context with their age.  It then returns an error status, so the runtime's
+// own handler prints its line and aborts as before.  ZK_FAULT_RECORDER=0 switches the registration off.
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <string.h>
+#include <unistd.h>
+#include <vector>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include "zk_internal.h"
+
+namespace {
+uint64_t now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct BlockRec { uintptr_t ptr; size_t size; const char *tag; uint64_t t_alloc, t_free; };
+constexpr size_t N_BLOCKS = (size_t)1 << 17;          // a ring: the newest records win
+BlockRec g_blocks[N_BLOCKS];
+std::atomic<uint64_t> g_n_blocks{0};
+std::mutex g_mu;                                      // registry of contexts
+std::vector<zk_ctx *> g_ctxs;
+std::atomic<int> g_registered{0};
+
+void describe(const char *what, uint64_t addr) {
+    hsa_amd_pointer_info_t info; memset(&info, 0, sizeof info); info.size = sizeof info;
+    hsa_status_t st = hsa_amd_pointer_info((const void *)addr, &info, nullptr, nullptr, nullptr);
+    static const char *kind[] = {"unknown to the runtime", "runtime allocation", "locked host memory", "graphics interop", "ipc", "reserved address", "virtual-memory handle"};
+    if (st != HSA_STATUS_SUCCESS) { fprintf(stderr, "[zk-fault]   %-28s 0x%llx: hsa_amd_pointer_info failed (%d)\n", what, (unsigned long long)addr, (int)st); return; }
+    const unsigned t = (unsigned)info.type;
+    if (t == 0) { fprintf(stderr, "[zk-fault]   %-28s 0x%llx: %s\n", what, (unsigned long long)addr, kind[0]); return; }
+    const uint64_t base = (uint64_t)(info.agentBaseAddress ? info.agentBaseAddress : info.hostBaseAddress);
+    fprintf(stderr, "[zk-fault]   %-28s 0x%llx: %s, block 0x%llx .. 0x%llx (%zu bytes), offset %lld, host base %p\n", what, (unsigned long long)addr, t < 7 ? kind[t] : "?",
+            (unsigned long long)base, (unsigned long long)(base + info.sizeInBytes), (size_t)info.sizeInBytes, (long long)(addr - base), info.hostBaseAddress);
+}
+
+void nearest_below(uint64_t addr) {
+    // walk down in pages (first 4 MiB), then in 2 MiB steps (to 2 GiB): the first address the runtime knows
+    for (int pass = 0; pass < 2; pass++) {
+        const uint64_t step = pass ? ((uint64_t)2 << 20) : 4096, lim = pass ? ((uint64_t)2 << 30) : ((uint64_t)4 << 20);
+        for (uint64_t d = step; d <= lim && d < addr; d += step) {
+            hsa_amd_pointer_info_t info; memset(&info, 0, sizeof info); info.size = sizeof info;
+            if (hsa_amd_pointer_info((const void *)(addr - d), &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || info.type == HSA_EXT_POINTER_TYPE_UNKNOWN) continue;
+            const uint64_t base = (uint64_t)(info.agentBaseAddress ? info.agentBaseAddress : info.hostBaseAddress), end = base + info.sizeInBytes;
+            fprintf(stderr, "[zk-fault]   nearest live allocation below: 0x%llx .. 0x%llx (%zu bytes); the address lies %lld bytes past its end\n", (unsigned long long)base,
+                    (unsigned long long)end, (size_t)info.sizeInBytes, (long long)(addr - end));
+            return;
+        }
+    }
+    fprintf(stderr, "[zk-fault]   no live allocation within 2 GiB below the address\n");
+}
+void nearest_above(uint64_t addr) {
+    for (int pass = 0; pass < 2; pass++) {
+        const uint64_t step = pass ? ((uint64_t)2 << 20) : 4096, lim = pass ? ((uint64_t)2 << 30) : ((uint64_t)4 << 20);
+        for (uint64_t d = step; d <= lim; d += step) {
+            hsa_amd_pointer_info_t info; memset(&info, 0, sizeof info); info.size = sizeof info;
+            if (hsa_amd_pointer_info((const void *)(addr + d), &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || info.type == HSA_EXT_POINTER_TYPE_UNKNOWN) continue;
+            const uint64_t base = (uint64_t)(info.agentBaseAddress ? info.agentBaseAddress : info.hostBaseAddress);
+            fprintf(stderr, "[zk-fault]   nearest live allocation above: 0x%llx .. 0x%llx (%zu bytes); it starts %lld bytes after the address\n", (unsigned long long)base,
+                    (unsigned long long)(base + info.sizeInBytes), (size_t)info.sizeInBytes, (long long)(base - addr));
+            return;
+        }
+    }
+    fprintf(stderr, "[zk-fault]   no live allocation within 2 GiB above the address\n");
+}
+
+void own_records(uint64_t addr, uint64_t t_now) {
+    const uint64_t n = g_n_blocks.load(std::memory_order_acquire), lo = n > N_BLOCKS ? n - N_BLOCKS : 0;
+    int hits = 0;
+    for (uint64_t i = n; i-- > lo && hits < 12;) {
+        const BlockRec &r = g_blocks[i % N_BLOCKS];
+        for (int k = -1; k <= 1; k++) {
+            const uint64_t a = addr + (int64_t)k * ((int64_t)1 << 32);
+            if (a < r.ptr || a >= r.ptr + r.size) continue;
+            fprintf(stderr, "[zk-fault]   library record: address%s inside %s 0x%llx .. 0x%llx (%zu bytes, offset %llu), taken %.3f s ago, %s", k < 0 ? " - 4 GiB" : k > 0 ? " + 4 GiB" : "",
+                    r.tag, (unsigned long long)r.ptr, (unsigned long long)(r.ptr + r.size), r.size, (unsigned long long)(a - r.ptr), (t_now - r.t_alloc) * 1e-6,
+                    r.t_free ? "" : "still held\n");
+            if (r.t_free) fprintf(stderr, "given back to the driver %.3f s ago\n", (t_now - r.t_free) * 1e-6);
+            hits++;
+        }
+    }
+    if (!hits) fprintf(stderr, "[zk-fault]   no block the library ever took from the driver contains the address (or the address +- 4 GiB): %llu records\n", (unsigned long long)(n - lo));
+}
+
+hsa_status_t on_event(const hsa_amd_event_t *ev, void *) {
+    if (!ev || ev->event_type != HSA_AMD_GPU_MEMORY_FAULT_EVENT) return HSA_STATUS_ERROR;
+    const uint64_t addr = ev->memory_fault.virtual_address, t_now = now_us();
+    fprintf(stderr, "[zk-fault] GPU memory fault at 0x%llx, reason bits 0x%x (pid %d)\n", (unsigned long long)addr, ev->memory_fault.fault_reason_mask, (int)getpid());
+    describe("the address", addr);
+    describe("the address + 4 GiB", addr + ((uint64_t)1 << 32));
+    describe("the address - 4 GiB", addr - ((uint64_t)1 << 32));
+    nearest_below(addr);
+    nearest_above(addr);
+    own_records(addr, t_now);
+    // the contexts: a thread that holds the registry lock never waits for the device, so this cannot block for long; give up after a second
+    bool locked = false;
+    for (int i = 0; i < 1000 && !(locked = g_mu.try_lock()); i++) usleep(1000);
+    fprintf(stderr, "[zk-fault] %zu contexts%s; their last launches, newest first (age in microseconds):\n", g_ctxs.size(), locked ? "" : " (registry busy: read without the lock)");
+    for (zk_ctx *c : g_ctxs) {
+        fprintf(stderr, "[zk-fault]   ctx %p stream %p host-challenger %d:", (void *)c, (void *)c->stream, c->host_transcript);
+        const unsigned n = c->launch_pos;
+        for (unsigned k = 0; k < ZK_LAUNCH_RING && k < n; k++) {
+            const zk_ctx::LaunchRec &r = c->launch_ring[(n - 1 - k) % ZK_LAUNCH_RING];
+            fprintf(stderr, " %s[%u x %u] %llu;", r.name ? r.name : "?", r.grid, r.block, (unsigned long long)(t_now - r.t_us));
+        }
+        fprintf(stderr, "\n");
+    }
+    if (locked) g_mu.unlock();
+    fflush(stderr);
+    return HSA_STATUS_ERROR;         // not handled: the runtime prints its own line and aborts, as without this handler
+}
+}  // namespace
+
+void zk_fault_note_block(const char *tag, const void *p, size_t n) {
+    if (!p) return;
+    if (strncmp(tag, "free-", 5) == 0) {
+        // the newest live record of this pointer
+        const uint64_t cnt = g_n_blocks.load(std::memory_order_acquire), lo = cnt > N_BLOCKS ? cnt - N_BLOCKS : 0;
+        for (uint64_t i = cnt; i-- > lo;) {
+            BlockRec &r = g_blocks[i % N_BLOCKS];
+            if (r.ptr == (uintptr_t)p && !r.t_free) { r.t_free = now_us(); return; }
+        }
+        return;
+    }
+    const uint64_t i = g_n_blocks.fetch_add(1, std::memory_order_acq_rel);
+    BlockRec &r = g_blocks[i % N_BLOCKS];
+    r.ptr = (uintptr_t)p; r.size = n; r.tag = tag; r.t_alloc = now_us(); r.t_free = 0;
+}
+
+void zk_fault_register_ctx(zk_ctx *c) {
+    { std::lock_guard<std::mutex> lk(g_mu); g_ctxs.push_back(c); }
+    if (g_registered.exchange(1)) return;
+    const char *e = getenv("ZK_FAULT_RECORDER");
+    if (e && atoi(e) == 0) return;
+    // the HIP runtime has initialised HSA by the time a context exists
+    if (hsa_amd_register_system_event_handler(on_event, nullptr) != HSA_STATUS_SUCCESS && getenv("ZK_ALLOC_TRACE")) fprintf(stderr, "[zk-fault] could not register the event handler\n");
+}
+void zk_fault_unregister_ctx(zk_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_ctxs.size(); i++) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + i); break; }
+}
+void zk_ctx::note_launch(const char *name, unsigned grid, unsigned block) {
+    LaunchRec &r = launch_ring[launch_pos % ZK_LAUNCH_RING];
+    r.name = name; r.grid = grid; r.block = block; r.t_us = now_us();
+    launch_pos++;
+}
+
+// Debug entry (include/zkgl.h): the report the handler would write for this address, without a fault -- how the recorder itself is tested.
+extern "C" int32_t zk_debug_fault_report(uint64_t addr) {
+    hsa_amd_event_t ev; memset(&ev, 0, sizeof ev);
+    ev.event_type = HSA_AMD_GPU_MEMORY_FAULT_EVENT; ev.memory_fault.virtual_address = addr; ev.memory_fault.fault_reason_mask = 0;
+    on_event(&ev, nullptr);
+    return g_registered.load() ? 0 : -1;
+}

@@ -286,6 +286,7 @@ static const PsdmTables *psdm_tables(zk_ctx *ctx) {
         if (hipMalloc(&d, sizeof(PsdmTables)) != hipSuccess) return nullptr;
         if (hipMemcpy(d, &host_tab, sizeof(PsdmTables), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
         dev_tab[ctx->device] = d;
+        ZK_ALLOC_TRACE("dev-poseidon-tables", d, sizeof(PsdmTables));
         if (ctx->sync_launch) fprintf(stderr, "[zk] PsdmTables at %p .. %p\n", d, (void *)((char *)d + sizeof(PsdmTables)));
     }
     ctx->d_psdm = dev_tab[ctx->device];

@@ -257,6 +257,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
             if (hipStreamWaitEvent(ctx->stream, side_ev[1], 0) != hipSuccess) { rc = ctx->fail(ZK_ERR_HIP, "prove: side stream"); break; }
             // device-side checks raised by the side context's kernels land in ITS error word: fold it into this proof's (first error
             // wins) and clear it, behind the join
+            ctx->note_launch("fold_err_word", 1, 1);
             hipLaunchKernelGGL(fold_err_word_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_err, ctx->side->d_err);
         }
         scratch_probe(ctx, d_zeta + 7);

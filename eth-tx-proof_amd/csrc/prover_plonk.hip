@@ -561,6 +561,7 @@ extern "C" int32_t zk_prove_plonk(zk_ctx *ctx, const zk_stark_config *cfgp, zk_p
                                                   st->gates_fn_is_module ? "hiprtc" : "build-time", kk + 1, st->gates_fns.size(), (unsigned)((L + 255) / 256));
                     // kernel 0 (the permutation part) spreads a point's (challenge, chunk) pairs over 8 threads: 32 points per workgroup
                     const unsigned grid = kk == 0 ? (unsigned)((L + 31) / 32) : (unsigned)((L + 255) / 256);
+                    ctx->note_launch(kk == 0 ? "plonk_quotient(compiled,0)" : "plonk_quotient(compiled,k)", grid, 256);
                     if (st->gates_fn_is_module) e = hipModuleLaunchKernel((hipFunction_t)st->gates_fns[kk], grid, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
                     else e = hipLaunchKernel(st->gates_fns[kk], dim3(grid), dim3(256), args, 0, ctx->stream);
                     if (e != hipSuccess) rc = ctx->fail(ZK_ERR_HIP, "plonk quotient: launch of a compiled gate kernel failed");

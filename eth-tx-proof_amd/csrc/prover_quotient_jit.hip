@@ -545,7 +545,7 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
     hipError_t e = hipSuccess;
     {
         ProfScope ps(ctx, "quotient_eval");
-        for (size_t j = 0; j < k.fns.size() && e == hipSuccess; j++) e = hipModuleLaunchKernel(k.fns[j], blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+        for (size_t j = 0; j < k.fns.size() && e == hipSuccess; j++) { ctx->note_launch(j ? "quotient_eval(compiled,k)" : "quotient_eval(compiled,0)", blocks, 256); e = hipModuleLaunchKernel(k.fns[j], blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr); }
     }
     ctx->release(state);                    // stream-ordered
     if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient jit: launch failed");

@@ -229,6 +229,7 @@ static zk_host_transcript *mailbox(zk_ctx *ctx) {
     if (hipHostMalloc((void **)&flags, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostMalloc((void **)&H->ring, RING, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); if (flags) hipHostFree(flags); delete H; return nullptr; }
     flags[0] = 0; flags[16] = 0;
+    ZK_ALLOC_TRACE("host-challenger-flags", flags, 256); ZK_ALLOC_TRACE("host-challenger-ring", H->ring, RING);
     H->gpu_done = flags; H->reply = flags + 16; H->ring_cap = RING;
     Service &S = service();
     { std::lock_guard<std::mutex> lk(S.mu); S.boxes.push_back(H); S.ensure(); }
@@ -244,6 +245,7 @@ void zk_host_transcript_destroy(zk_ctx *ctx) {
     Service &S = service();
     { std::lock_guard<std::mutex> lk(S.mu); for (size_t i = 0; i < S.boxes.size(); i++) if (S.boxes[i] == H) { S.boxes.erase(S.boxes.begin() + i); break; } }
     { std::unique_lock<std::mutex> lk(H->mu); H->idle_cv.wait(lk, [H] { return !H->busy; }); }       // nobody can pick it any more
+    ZK_ALLOC_TRACE("free-host-challenger-flags", H->gpu_done, 256); ZK_ALLOC_TRACE("free-host-challenger-ring", H->ring, 0);
     hipHostFree((void *)H->gpu_done); hipHostFree(H->ring);
     delete H;
     ctx->hmb = nullptr;
@@ -326,6 +328,7 @@ int32_t zk_host_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops
     const u64 seq = job.seq;
     if (job.needs_gpu) {
         ProfScope ps(ctx, "transcript_host_gather");
+        ctx->note_launch("host_transcript_gather", 1, 256);
         hipLaunchKernelGGL(host_transcript_gather_kernel, dim3(1), dim3(256), 0, ctx->stream, gin, H->gpu_done, seq);
     }
     Service &S = service();
@@ -340,6 +343,7 @@ int32_t zk_host_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops
             while (*H->reply < seq) _mm_pause();
         }
         ProfScope ps(ctx, "transcript_host_scatter");
+        ctx->note_launch("host_transcript_wait+scatter", 1, 256);
         hipLaunchKernelGGL(host_transcript_scatter_kernel, dim3(1), dim3(256), 0, ctx->stream, gout);
     }
     return ZK_OK;

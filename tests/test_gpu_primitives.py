@@ -392,3 +392,30 @@ def test_packed_upload_from_pinned_memory_then_a_proof_straight_away(zk, orc):
             del src
         finally:
             c.close()
+
+
+@pytest.mark.gpu
+def test_fault_recorder_names_the_owner_of_an_address(zk, capfd):
+    """csrc/fault_recorder.hip: the report the library's handler writes on a GPU memory fault, produced here WITHOUT a fault
+    (zk_debug_fault_report) for an address inside a block this context holds: the runtime's view (a live allocation), the library's own
+    record (tag, offset, still held) and the context's last launches must all be there."""
+    import ctypes as C
+    c = zk.Context(0)
+    try:
+        nbytes = 3 << 20                             # a driver allocation of its own (2 MiB and more are never sub-allocated)
+        d = c.dev_alloc(nbytes)
+        c.upload(d, np.arange(1024, dtype=np.uint64))
+        c.two_to_one(np.zeros((4, 4), dtype=np.uint64), np.ones((4, 4), dtype=np.uint64))     # any launch: something for the launch ring
+        addr = int(d) + 4096 + 8
+        f = zk.lib().zk_debug_fault_report
+        f.argtypes, f.restype = [C.c_uint64], C.c_int32
+        capfd.readouterr()
+        assert f(addr) == 0, "the handler is not registered"
+        err = capfd.readouterr().err
+        assert "[zk-fault] GPU memory fault at 0x%x" % addr in err
+        assert "runtime allocation" in err and "offset 4104" in err
+        assert "library record: address inside dev-block" in err and "still held" in err
+        assert "last launches" in err and "[" in err.split("last launches")[1]
+        c.dev_free(d)
+    finally:
+        c.close()
