@@ -92,6 +92,32 @@ void own_records(uint64_t addr, uint64_t t_now) {
     if (!hits) fprintf(stderr, "[zk-fault]   no block the library ever took from the driver contains the address (or the address +- 4 GiB): %llu records\n", (unsigned long long)(n - lo));
 }
 
+void address_space_near(uint64_t addr, uint64_t t_now) {
+    // where the address sits among the library's live blocks, and what the process has mapped around it
+    const uint64_t n = g_n_blocks.load(std::memory_order_acquire), lo = n > N_BLOCKS ? n - N_BLOCKS : 0;
+    uint64_t mn = ~(uint64_t)0, mx = 0, live = 0, newest_free = 0; const BlockRec *nf = nullptr;
+    for (uint64_t i = lo; i < n; i++) {
+        const BlockRec &r = g_blocks[i % N_BLOCKS];
+        if (r.t_free) { if (r.t_free > newest_free) { newest_free = r.t_free; nf = &r; } continue; }
+        live++; if (r.ptr < mn) mn = r.ptr; if (r.ptr + r.size > mx) mx = r.ptr + r.size;
+    }
+    fprintf(stderr, "[zk-fault]   library blocks held: %llu, spanning 0x%llx .. 0x%llx\n", (unsigned long long)live, (unsigned long long)mn, (unsigned long long)mx);
+    if (nf) fprintf(stderr, "[zk-fault]   last block given back to the driver: %s 0x%llx (%zu bytes) %.3f s ago\n", nf->tag, (unsigned long long)nf->ptr, nf->size, (t_now - nf->t_free) * 1e-6);
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f) return;
+    char line[512]; int shown = 0;
+    while (fgets(line, sizeof line, f) && shown < 24) {
+        unsigned long long a = 0, b = 0;
+        if (sscanf(line, "%llx-%llx", &a, &b) != 2) continue;
+        if (b + ((uint64_t)16 << 20) < addr || a > addr + ((uint64_t)16 << 20)) continue;
+        size_t len = strlen(line); if (len && line[len - 1] == '\n') line[len - 1] = 0;
+        fprintf(stderr, "[zk-fault]   maps: %s%s\n", line, (a <= addr && addr < b) ? "   <-- contains the address" : "");
+        shown++;
+    }
+    fclose(f);
+    if (!shown) fprintf(stderr, "[zk-fault]   maps: nothing mapped within 16 MiB of the address\n");
+}
+
 hsa_status_t on_event(const hsa_amd_event_t *ev, void *) {
     if (!ev || ev->event_type != HSA_AMD_GPU_MEMORY_FAULT_EVENT) return HSA_STATUS_ERROR;
     const uint64_t addr = ev->memory_fault.virtual_address, t_now = now_us();
@@ -102,6 +128,7 @@ hsa_status_t on_event(const hsa_amd_event_t *ev, void *) {
     nearest_below(addr);
     nearest_above(addr);
     own_records(addr, t_now);
+    address_space_near(addr, t_now);
     // the contexts: a thread that holds the registry lock never waits for the device, so this cannot block for long; give up after a second
     bool locked = false;
     for (int i = 0; i < 1000 && !(locked = g_mu.try_lock()); i++) usleep(1000);
