@@ -140,15 +140,23 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
                 if not np.array_equal(r, root0):
                     raise RuntimeError("worker %d: another root proof than the first unit's" % s)
                 done.wait()
+            except threading.BrokenBarrierError:
+                pass                               # another worker failed first
             except Exception as e:
+                import traceback
                 errs.append(e)
+                sys.stderr.write("[bench] transaction worker %d failed: %r\n%s" % (s, e, traceback.format_exc()))
+                sys.stderr.flush()
                 go.abort(); done.abort()
             finally:
                 st.drop_ctx()
         th = [threading.Thread(target=worker, args=(s,)) for s in range(inflight)]
         for t in th:
             t.start()
-        go.wait()
+        try:
+            go.wait()
+        except threading.BrokenBarrierError:
+            pass                                   # a worker failed during its warm-up: its error is raised below
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if os.environ.get("ZK_VA_PROBE"):          # debug: the runtime's view of the address windows the unexplained GPU faults named, with every context alive and busy
@@ -156,7 +164,10 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
             import va_probe
             time.sleep(0.2)
             va_probe.probe("transactions in flight")
-        done.wait()
+        try:
+            done.wait()
+        except threading.BrokenBarrierError:
+            pass                                   # a worker failed: what it raised is in errs
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         for t in th:

@@ -9,8 +9,9 @@
 // writes to stderr: the address and reason bits; what the RUNTIME knows about the address and about the same address 4 GiB higher and lower
 // (hsa_amd_pointer_info covers every allocation of the process, the HIP runtime's own included); the nearest live allocation below the
 // address and the distance to its end (an overrun reads as a few bytes to a few KB past an end; a stale pointer does not); the library's own
-// records that contain the address; the last launches of every context with their age.  It then returns an error status, so the runtime's
-// own handler prints its line and aborts as before.  ZK_FAULT_RECORDER=0 switches the registration off.
+// records that contain the address; the last launches of every context with their age.  It then ends the process (exit code 134): the runtime's
+// own handler would abort it anyway, and on this stack a faulted process otherwise lingers until something kills it.  ZK_FAULT_EXIT=0 returns
+// an error status instead (the runtime prints its line and aborts as before); ZK_FAULT_RECORDER=0 switches the registration off.
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -31,6 +32,7 @@ std::atomic<uint64_t> g_n_blocks{0};
 std::mutex g_mu;                                      // registry of contexts
 std::vector<zk_ctx *> g_ctxs;
 std::atomic<int> g_registered{0};
+thread_local bool g_dry_run = false;                  // zk_debug_fault_report: the report only
 
 void describe(const char *what, uint64_t addr) {
     hsa_amd_pointer_info_t info; memset(&info, 0, sizeof info); info.size = sizeof info;
@@ -144,6 +146,16 @@ hsa_status_t on_event(const hsa_amd_event_t *ev, void *) {
     }
     if (locked) g_mu.unlock();
     fflush(stderr);
+    // The runtime's own handler would now print its line and abort().  On this stack a process that has faulted does not go away after that
+    // line: every faulting run of rounds 3 and 4 sat there until its timeout killed it (minutes of a GPU box each time).  The process is lost
+    // either way, so it ends here, at once and without a core image of a few hundred GB of mappings; ZK_FAULT_EXIT=0 hands over to the
+    // runtime's handler instead.  (zk_debug_fault_report never gets here.)
+    static const bool exit_here = !(getenv("ZK_FAULT_EXIT") && atoi(getenv("ZK_FAULT_EXIT")) == 0);
+    if (exit_here && !g_dry_run) {
+        fprintf(stderr, "Memory access fault by GPU on address 0x%llx (reported by libzkgl_hip's handler, see the [zk-fault] lines above); the process exits with code 134\n", (unsigned long long)addr);
+        fflush(stderr);
+        _exit(134);
+    }
     return HSA_STATUS_ERROR;         // not handled: the runtime prints its own line and aborts, as without this handler
 }
 }  // namespace
@@ -186,6 +198,8 @@ void zk_ctx::note_launch(const char *name, unsigned grid, unsigned block) {
 extern "C" int32_t zk_debug_fault_report(uint64_t addr) {
     hsa_amd_event_t ev; memset(&ev, 0, sizeof ev);
     ev.event_type = HSA_AMD_GPU_MEMORY_FAULT_EVENT; ev.memory_fault.virtual_address = addr; ev.memory_fault.fault_reason_mask = 0;
+    g_dry_run = true;
     on_event(&ev, nullptr);
+    g_dry_run = false;
     return g_registered.load() ? 0 : -1;
 }

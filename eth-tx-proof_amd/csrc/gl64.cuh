@@ -172,7 +172,7 @@ template <bool EXACT> struct glx {
             "v_subbrev_co_u32 %[dh], vcc, 0, %[rh], vcc\n\t"
             "s_or_b64 %[fl], %[fl], vcc\n\t"
             : [dl] "=&v"(dl), [dh] "=&v"(dh), [fl] "+s"(fl)
-            : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h1), [cy] "s"(cy) : "vcc");
+            : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h1), [cy] "s"(cy) : "vcc", "scc");
         return ((u64)dh << 32) | dl;
     }
     // lo + hi*2^64 - cy  ->  canonical residue unless a rare repair was skipped (then fl != 0)
@@ -186,11 +186,11 @@ template <bool EXACT> struct glx {
             "v_subbrev_co_u32 %[dh], vcc, 0, %[rh], vcc\n\t"
             "s_or_b64 %[fl], %[fl], vcc\n\t"
             : [dl] "=&v"(dl), [dh] "=&v"(dh), [fl] "+s"(fl)
-            : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h1), [cy] "s"(cy) : "vcc");
+            : [rl] "v"(rl), [rh] "v"(rh), [h] "v"(h1), [cy] "s"(cy) : "vcc", "scc");
         d = ((u64)dh << 32) | dl;
         asm("v_cmp_ge_u64 vcc, %[d], %[p]\n\t"
             "s_or_b64 %[fl], %[fl], vcc\n\t"
-            : [fl] "+s"(fl) : [d] "v"(d), [p] "s"((u64)GL_P) : "vcc");
+            : [fl] "+s"(fl) : [d] "v"(d), [p] "s"((u64)GL_P) : "vcc", "scc");
         return d;
     }
     // ---- weak butterflies for the NTT networks.  Operands and results are ANY representative in [0, 2^64) of their residue:
@@ -240,7 +240,7 @@ template <bool EXACT> struct glx {
             "s_or_b64 %[fl], %[fl], %[k3]\n\t"
             : [a1] "+v"(a1), [a2] "+v"(a2), [d1l] "+v"(d1l), [d1h] "+v"(d1h), [d2l] "+v"(d2l), [d2h] "+v"(d2h), [fl] "+s"(fl),
               [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
-            : [m0] "v"(m0), [m1] "v"(m1), [m2] "v"(m2), [m3] "v"(m3));
+            : [m0] "v"(m0), [m1] "v"(m1), [m2] "v"(m2), [m3] "v"(m3) : "scc");
         u1 = a1; v1 = ((u64)d1h << 32) | d1l; u2 = a2; v2 = ((u64)d2h << 32) | d2l;
 #endif
     }
@@ -267,7 +267,7 @@ template <bool EXACT> struct glx {
             "v_subbrev_co_u32 %[dh], %[k1], 0, %[dh], %[k1]\n\t"
             "s_or_b64 %[fl], %[fl], %[k1]\n\t"
             : [a] "+v"(a), [dl] "+v"(dl), [dh] "+v"(dh), [fl] "+s"(fl), [k0] "=&s"(k0), [k1] "=&s"(k1)
-            : [m0] "v"(m0), [m1] "v"(m1));
+            : [m0] "v"(m0), [m1] "v"(m1) : "scc");
         u = a; v = ((u64)dh << 32) | dl;
 #endif
     }
@@ -291,7 +291,7 @@ template <bool EXACT> struct glx {
                 "s_nop 1\n\t"
                 "v_subbrev_co_u32 %[dh], vcc, 0, %[th], vcc\n\t"
                 "s_or_b64 %[fl], %[fl], vcc\n\t"
-                : [dl] "=&v"(dl), [dh] "=&v"(dh), [fl] "+s"(fl) : [tl] "v"(tl), [th] "v"(th), [h] "v"(wc) : "vcc");
+                : [dl] "=&v"(dl), [dh] "=&v"(dh), [fl] "+s"(fl) : [tl] "v"(tl), [th] "v"(th), [h] "v"(wc) : "vcc", "scc");
             return ((u64)dh << 32) | dl;
         }
         {
@@ -321,7 +321,7 @@ template <bool EXACT> struct glx {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm("v_cmp_ge_u64 vcc, %[x], %[p]\n\t"
             "s_or_b64 %[fl], %[fl], vcc\n\t"
-            : [fl] "+s"(fl) : [x] "v"(x), [p] "s"((u64)GL_P) : "vcc");
+            : [fl] "+s"(fl) : [x] "v"(x), [p] "s"((u64)GL_P) : "vcc", "scc");
 #endif
     }
     // sum_i x_i * c_i with small constants c_i (their sum below 2^31; x_i any 64-bit representatives): the shape of an MDS row.  Two 64-bit

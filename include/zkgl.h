@@ -68,8 +68,9 @@ int64_t zk_host_challenger_script(const int32_t *ops, uint32_t n_ops, const uint
                                   uint64_t state_out[12]);
 /* Flight recorder (csrc/fault_recorder.hip): the library registers a handler for the runtime's GPU-memory-fault event that writes to stderr
  * what the runtime and the library know about the faulting address (and the same address 4 GiB higher / lower), the nearest live allocations
- * on both sides, and every context's last launches; the runtime's own handler then aborts the process as it would have anyway.
- * ZK_FAULT_RECORDER=0 in the environment leaves the handler unregistered.  zk_debug_fault_report writes that report for any address without
+ * on both sides, and every context's last launches, and then ends the process with exit code 134 (the runtime's own handler would abort
+ * it anyway; on the measured stack a faulted process otherwise lingers until it is killed).  ZK_FAULT_EXIT=0: report, then the runtime's
+ * handler as before.  ZK_FAULT_RECORDER=0 in the environment leaves the handler unregistered.  zk_debug_fault_report writes that report for any address without
  * a fault (returns 0 when the handler is registered). */
 int32_t zk_debug_fault_report(uint64_t addr);
 int32_t zk_ctx_synchronize(zk_ctx *ctx);

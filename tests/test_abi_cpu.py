@@ -196,6 +196,11 @@ def test_segmented_constraint_kernel_source_compiles_for_gfx950_without_scratch(
     import kernel_resources as KR
     ks = KR.kernels(str(obj))
     assert len(ks) == 3 and all(k["scratch"] == 0 and k["vgpr_spill"] == 0 and not k["dynamic_stack"] for k in ks), ks
+    # ... and no scalar add-with-carry whose carry an asm block of the field header could have overwritten (section 9.4's defect: the
+    # generated kernels are where it was first seen in shipped code)
+    import asm_clobber_audit as A
+    pairs, sites = A.scc_pairs_in_code_objects(str(obj))
+    assert pairs > 0 and not sites, sites
     # a narrow AIR keeps the single-function form (the kernels built with the library depend on that text)
     small = air.cpu_like_air(93, 19)
     assert L.zk_quotient_kernel_source(small.ref, C.c_uint32(2), C.c_uint32(1), None, C.c_size_t(0), C.byref(ln), C.byref(kh)) == 0
@@ -234,6 +239,30 @@ def test_no_shipped_kernel_uses_scratch():
     assert not bad, "kernels with scratch: %s" % bad
     # two 512-thread workgroups of the NTT pass kernel per compute unit: at most 128 registers
     assert all(k["vgpr"] + k["agpr"] <= 128 for k in ks if "ntt_fast_kernel" in k["name"])
+
+
+def test_inline_asm_declares_every_implicit_register_it_writes():
+    """The cause of the GPU memory faults of rounds 1-4: asm blocks ending in `s_or_b64 flag, flag, vcc` -- a SCALAR
+    instruction, which writes SCC -- declared only "vcc"; hipcc forms 64-bit scalar addresses as s_add_u32 / s_addc_u32 with the carry in
+    SCC, scheduled such a block between the two, and the carry into a pointer's upper half was lost whenever the lower half wrapped (an
+    access behind a 4 GiB boundary inside a block that straddles one).  Both sides are checked: every asm statement of the sources against
+    the implicit registers its text writes (tools/asm_clobber_audit.py), and every scalar add / add-with-carry pair of the BUILT code
+    objects for an instruction in between that overwrites SCC (the compiler's own save / restore idiom excepted)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import asm_clobber_audit as A
+    from eth_tx_proof_amd import lib as zl
+    n, bad = A.audit()
+    assert n >= 200, "the audit saw only %d asm statements" % n
+    assert not bad, "\n".join(bad)
+    # the checker itself: the defective shape must be flagged
+    bad_stmt = 'asm("v_cmp_ge_u64 vcc, %[x], %[p]\\n\\t" "s_or_b64 %[fl], %[fl], vcc\\n\\t" : [fl] "+s"(fl) : [x] "v"(x), [p] "s"(p) : "vcc")'
+    assert A.check_statement(bad_stmt, {}) and not A.check_statement(bad_stmt[:-1] + ', "scc")', {})
+    zl.build()
+    pairs, sites = A.scc_pairs_in_code_objects(zl._SO)
+    assert pairs > 10000, "only %d scalar add / add-with-carry pairs found: is the disassembler there?" % pairs
+    assert not sites, "SCC overwritten between a scalar add and its add-with-carry:\n" + "\n".join(sites[:20])
 
 
 def test_host_challenger_permutation_and_sponge_against_upstream_vectors_and_the_oracle(zk):

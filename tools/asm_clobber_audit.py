@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Every inline-asm statement of the device sources against the implicit registers its text touches.
+
+Round 4's memory fault: asm blocks of gl64.cuh ended in `s_or_b64 fl, fl, vcc` -- a scalar instruction, which
+writes SCC -- and declared only "vcc" as clobbered.  hipcc forms 64-bit scalar addresses as s_add_u32 / s_addc_u32 with the carry in SCC
+and was free to schedule such a block between the two: the carry into the upper half of a pointer was lost whenever the lower half
+wrapped, i.e. for accesses behind a 4 GiB boundary inside a block that straddles one.  This audit parses every asm statement and fails when
+  * its text names vcc and "vcc" is not among its clobbers (or operands),
+  * it contains a scalar ALU / compare instruction (anything s_* that writes SCC) and "scc" is not among its clobbers,
+  * it writes exec or m0 without declaring it.
+tests/test_abi_cpu.py runs it over csrc/ and tools/; tools/scc_pairs_in_code_objects() checks the built code objects for the same
+pattern from the other side (an SCC writer between a scalar add and its add-with-carry)."""
+import glob
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# scalar instructions that leave SCC alone; every other s_* mnemonic is taken to write it
+NO_SCC = set("""s_nop s_waitcnt s_mov_b32 s_mov_b64 s_barrier s_sleep s_setprio s_cselect_b32 s_cselect_b64 s_mul_i32 s_mul_hi_u32 s_mul_hi_i32
+s_movk_i32 s_getpc_b64 s_branch s_cbranch_scc0 s_cbranch_scc1 s_cbranch_vccz s_cbranch_vccnz s_cbranch_execz s_cbranch_execnz s_endpgm
+s_bitset1_b32 s_bitset0_b32 s_sext_i32_i16 s_sext_i32_i8 s_pack_ll_b32_b16 s_cmov_b32 s_cmov_b64 s_brev_b32 s_brev_b64 s_load_dword
+s_load_dwordx2 s_load_dwordx4 s_load_dwordx8 s_load_dwordx16 s_memtime s_memrealtime s_dcache_wb s_setreg_b32 s_getreg_b32 s_sethalt
+s_mulk_i32 s_ff1_i32_b32 s_ff1_i32_b64 s_flbit_i32_b32 s_flbit_i32_b64 s_icache_inv s_trap s_code_end s_set_gpr_idx_on s_set_gpr_idx_off""".split())
+
+
+def asm_statements(text):
+    """(offset, statement text) of every asm(...) / asm volatile(...) in a C++ source, macros expanded by the caller"""
+    out = []
+    for m in re.finditer(r"\basm(?:\s+volatile)?\s*\(", text):
+        j, depth = m.end(), 1
+        while depth and j < len(text):
+            c = text[j]
+            if c == '"':
+                j += 1
+                while text[j] != '"':
+                    j += 2 if text[j] == "\\" else 1
+            elif c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+            j += 1
+        out.append((m.start(), text[m.start():j]))
+    return out
+
+
+def split_sections(stmt):
+    """template string, outputs, inputs, clobbers of one asm statement (top-level colons)"""
+    body = stmt[stmt.index("(") + 1:-1]
+    parts, cur, depth, i = [], [], 0, 0
+    while i < len(body):
+        c = body[i]
+        if c == '"':
+            k = i + 1
+            while body[k] != '"':
+                k += 2 if body[k] == "\\" else 1
+            cur.append(body[i:k + 1]); i = k + 1; continue
+        if c in "([":
+            depth += 1
+        elif c in ")]":
+            depth -= 1
+        if c == ":" and depth == 0 and not (i + 1 < len(body) and body[i + 1] == ":") and not (i and body[i - 1] == ":"):
+            parts.append("".join(cur)); cur = []
+        else:
+            cur.append(c)
+        i += 1
+    parts.append("".join(cur))
+    parts += [""] * (4 - len(parts))
+    template = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', parts[0]))
+    return template, parts[1], parts[2], parts[3]
+
+
+def check_statement(stmt, macros):
+    for name, val in macros.items():              # generated bodies and clobber lists come in through macros
+        stmt = re.sub(r"\b%s\b" % re.escape(name), lambda _m, v=val: v, stmt)
+    template, outs, ins, clob = split_sections(stmt)
+    template = template.replace("\\n", "\n").replace("\\t", " ")
+    clobbers = set(re.findall(r'"([^"]+)"', clob))
+    problems = []
+    ops = [ln.strip().split()[0] for ln in template.split("\n") if ln.strip() and not ln.strip().startswith((";", "//"))]
+    if re.search(r"\bvcc(_lo|_hi)?\b", template) and "vcc" not in clobbers:
+        problems.append('names vcc without a "vcc" clobber')
+    scc = sorted({o for o in ops if o.startswith("s_") and o not in NO_SCC})
+    if scc and "scc" not in clobbers:
+        problems.append('%s write(s) SCC without an "scc" clobber' % ", ".join(scc))
+    for reg in ("exec", "m0"):
+        if re.search(r"\b(s_\w+|v_cmpx\w*|v_readfirstlane\w*)\s+%s\b" % reg, template) and reg not in clobbers:
+            problems.append("writes %s without declaring it" % reg)
+    if re.search(r"\bv_cmpx", template) and "exec" not in clobbers:
+        problems.append("v_cmpx writes exec without declaring it")
+    return problems
+
+
+def collect_macros(paths):
+    macros = {}
+    for p in paths:
+        txt = open(p, errors="replace").read()
+        for m in re.finditer(r"^#define\s+(\w+)\s+((?:.*\\\n)*.*)$", txt, re.M):
+            body = m.group(2).replace("\\\n", " ")
+            if '"' in body and ("ASM" in m.group(1) or "CLOBBER" in m.group(1)):
+                macros[m.group(1)] = body
+    return macros
+
+
+def audit(dirs=None):
+    dirs = dirs or [os.path.join(ROOT, "eth-tx-proof_amd", "csrc"), os.path.join(ROOT, "tools")]
+    files = [f for d in dirs for ext in ("*.cuh", "*.hip", "*.h", "*.inc") for f in sorted(glob.glob(os.path.join(d, ext)))]
+    macros = collect_macros(files)
+    bad, n = [], 0
+    for f in files:
+        if f.endswith("gl64_src.inc"):
+            continue                               # gl64.cuh as a string literal for hiprtc: the same text
+        txt = open(f, errors="replace").read()
+        for off, stmt in asm_statements(txt):
+            n += 1
+            for pr in check_statement(stmt, macros):
+                bad.append("%s:%d: %s" % (os.path.relpath(f, ROOT), txt.count("\n", 0, off) + 1, pr))
+    return n, bad
+
+
+def scc_pairs_in_code_objects(lib=None, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    """The same defect seen from the built code: an instruction that writes SCC -- other than the compiler's own save/restore idiom
+    (s_cselect_b64 mask, -1, 0 ... s_cmp_lg_u64 mask, 0) -- between an s_add_u32 / s_sub_u32 and the s_addc_u32 / s_subb_u32 that consumes its carry.
+    Returns (number of add/addc pairs seen, list of offending sites)."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    lib = lib or os.path.join(ROOT, "eth-tx-proof_amd", "csrc", "libzkgl_hip.so")
+    images = [lib] if lib.endswith(".co") else None
+    blobs = [open(lib, "rb").read()] if images else [[x for x in co if isinstance(x, (bytes, bytearray))][0] for co in kr.code_objects(lib)]
+    pairs, sites = 0, []
+    for blob in blobs:
+        with tempfile.NamedTemporaryFile(suffix=".co") as tf:
+            tf.write(blob); tf.flush()
+            asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", tf.name], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode(errors="replace")
+        fn, pend, dirty, saved = None, None, None, None
+        for ln in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                fn, pend = m.group(1), None
+                continue
+            t = ln.strip().split("//")[0].strip()
+            if not t or t.endswith(":"):
+                continue
+            op = t.split()[0]
+            if op in ("s_add_u32", "s_sub_u32"):
+                pend, dirty, saved = [t], None, None
+                continue
+            if pend is None:
+                continue
+            if op in ("s_addc_u32", "s_subb_u32"):
+                pairs += 1
+                if dirty:
+                    sites.append("%s: %s ... %s ... %s" % (fn, pend[0], dirty, t))
+                pend = None
+                continue
+            pend.append(t)
+            if op == "s_cselect_b64" and t.replace(" ", "").endswith(",-1,0") and dirty is None:
+                saved = t.split()[1].rstrip(",")                         # the compiler parks SCC in a mask ...
+            elif op == "s_cmp_lg_u64" and saved and t.split()[1].rstrip(",") == saved and dirty is None:
+                saved = None                                             # ... and brings it back: SCC is the carry again
+            elif op.startswith("s_") and op not in NO_SCC:
+                dirty = dirty or t
+            if len(pend) > 400 or op in ("s_endpgm", "s_branch", "s_setpc_b64", "s_swappc_b64") or op.startswith("s_cbranch"):
+                pend = None
+    return pairs, sites
+
+
+if __name__ == "__main__":
+    n, bad = audit()
+    print("%d asm statements, %d problems" % (n, len(bad)))
+    for b in bad:
+        print("  " + b)
+    if "--code" in sys.argv:
+        pairs, sites = scc_pairs_in_code_objects(sys.argv[sys.argv.index("--code") + 1] if len(sys.argv) > sys.argv.index("--code") + 1 else None)
+        print("%d scalar add / add-with-carry pairs in the code objects, %d with SCC overwritten in between" % (pairs, len(sites)))
+        for s in sites[:20]:
+            print("  " + s)
+        bad += sites
+    sys.exit(1 if bad else 0)

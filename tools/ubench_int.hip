@@ -48,7 +48,7 @@ DEF_KERNEL32(k_addc_pair, asm volatile("v_add_co_u32 %0, vcc, %1, %0\n\tv_addc_c
 DEF_KERNEL32(k_mov_b32, asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b)))
 DEF_KERNEL32(k_and_b32, asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b)))
 DEF_KERNEL32(k_lshlrev_b32, asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i])))
-DEF_KERNEL32(k_cndmask_vcc, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : ))
+DEF_KERNEL32(k_cndmask_vcc, asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"))
 DEF_KERNEL32(k_cndmask_e64, asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(b) : "s10", "s11"))
 DEF_KERNEL32(k_add_co_e32, asm volatile("v_add_co_u32 %0, vcc, %1, %0" : "+v"(a[i]) : "v"(b) : "vcc"))
 DEF_KERNEL32(k_sub_u32, asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)))
