@@ -26,6 +26,26 @@ void *zk_ctx::alloc(size_t bytes) {
         size_t mapped = (bytes + gran - 1) / gran * gran;
         void *va = nullptr; hipMemGenericAllocationHandle_t h;
         hipMemAccessDesc ad = {}; ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+        if (efence == 2) {
+            // ZK_ALLOC_EFENCE=2: every block STRADDLES a 4 GiB boundary, the boundary in its middle.  The faults of rounds 1-4 were pointers that
+            // lost the carry into their upper half (an asm block overwrote SCC between the compiler's s_add_u32 and s_addc_u32, DESIGN.md
+            // section 9.4): they needed a block that happens to straddle such a boundary, about one allocation in a thousand.  Under this
+            // allocator every kernel of a test run meets that layout in every buffer.
+            const size_t G4 = (size_t)1 << 32, half_lo = (bytes / 2) & ~(size_t)255;
+            const size_t k_lo = (half_lo + gran - 1) / gran, k_hi = (bytes - half_lo + gran - 1) / gran;
+            mapped = (k_lo + k_hi) * gran;
+            if (hipMemAddressReserve(&va, G4 + mapped, gran, nullptr, 0) != hipSuccess) { last_error = "straddle allocation: address range"; return nullptr; }
+            const size_t B = ((size_t)va + k_lo * gran + G4 - 1) & ~(G4 - 1);
+            void *m = (void *)(B - k_lo * gran);
+            if (hipMemCreate(&h, mapped, &prop, 0) != hipSuccess || hipMemMap(m, mapped, 0, h, 0) != hipSuccess || hipMemSetAccess(m, mapped, &ad, 1) != hipSuccess) {
+                last_error = "straddle allocation failed"; return nullptr;
+            }
+            p = (void *)(B - half_lo);
+            block_size[p] = bytes; bytes_allocated += bytes;
+            ZK_ALLOC_TRACE("dev-block-straddling", p, bytes);
+            if (sync_launch) fprintf(stderr, "[zk %p] straddle %zu at %p .. %p\n", (void *)this, bytes, p, (void *)((char *)p + bytes));
+            return p;
+        }
         if (hipMemAddressReserve(&va, mapped + gran, gran, nullptr, 0) != hipSuccess || hipMemCreate(&h, mapped, &prop, 0) != hipSuccess ||
             hipMemMap(va, mapped, 0, h, 0) != hipSuccess || hipMemSetAccess(va, mapped, &ad, 1) != hipSuccess) {
             last_error = "efence allocation failed"; return nullptr;

@@ -400,6 +400,8 @@ def test_fault_recorder_names_the_owner_of_an_address(zk, capfd):
     (zk_debug_fault_report) for an address inside a block this context holds: the runtime's view (a live allocation), the library's own
     record (tag, offset, still held) and the context's last launches must all be there."""
     import ctypes as C
+    if os.environ.get("ZK_ALLOC_EFENCE"):
+        pytest.skip("the debug allocators place blocks through the virtual-memory API: other tags, another runtime pointer type")
     c = zk.Context(0)
     try:
         nbytes = 3 << 20                             # a driver allocation of its own (2 MiB and more are never sub-allocated)
