@@ -102,9 +102,10 @@ int32_t zk_ctx::upload_small(void *d_dst, const void *src, size_t bytes) {
 
 // Synchronous copies between caller memory and the device.  The caller's memory is pageable as a rule (numpy arrays, std::vector): handed
 // to hipMemcpyAsync directly, the runtime pins its pages on the fly and releases them when the copy retires -- with dozens of threads doing
-// that at once (eight transactions x four contexts: Merkle roots of child proofs, public-input hashes, caps coming back) one run in 16 ended
-// in "Memory access fault by GPU" at an address inside a worker thread's malloc arena.  Every such copy now bounces through pinned memory
-// owned by the context, 4 MiB at a time; big uploads keep the double-buffered path of upload_large.
+// that at once (eight transactions x four contexts: Merkle roots of child proofs, public-input hashes, caps coming back) that is a lot of
+// registration traffic in the driver.  Every such copy bounces through pinned memory owned by the context, 4 MiB at a time; big uploads keep
+// the double-buffered path of upload_large.  (Round 4 suspected these copies of a GPU memory fault; the fault was a lost pointer carry in
+// three kernels, DESIGN.md section 9 -- the bounce buffers stay because they keep the runtime's pin / unpin path out of the proofs.)
 #define ZK_IO_BYTES ((size_t)4 << 20)
 static bool io_buffer(zk_ctx *c) {
     if (c->h_io) return true;
