@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string.h>
 #include <unistd.h>
+#include <unordered_map>
 #include <vector>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -162,18 +163,24 @@ hsa_status_t on_event(const hsa_amd_event_t *ev, void *) {
 
 void zk_fault_note_block(const char *tag, const void *p, size_t n) {
     if (!p) return;
+    // driver allocations are rare (the contexts cache their blocks): a lock and an index of the live records cost nothing that matters
+    static std::mutex mu;
+    static std::unordered_map<uintptr_t, uint64_t> live;          // pointer -> record number
+    std::lock_guard<std::mutex> lk(mu);
     if (strncmp(tag, "free-", 5) == 0) {
-        // the newest live record of this pointer
-        const uint64_t cnt = g_n_blocks.load(std::memory_order_acquire), lo = cnt > N_BLOCKS ? cnt - N_BLOCKS : 0;
-        for (uint64_t i = cnt; i-- > lo;) {
-            BlockRec &r = g_blocks[i % N_BLOCKS];
-            if (r.ptr == (uintptr_t)p && !r.t_free) { r.t_free = now_us(); return; }
-        }
+        auto it = live.find((uintptr_t)p);
+        if (it == live.end()) return;
+        const uint64_t cnt = g_n_blocks.load(std::memory_order_acquire);
+        BlockRec &r = g_blocks[it->second % N_BLOCKS];
+        if (cnt - it->second <= N_BLOCKS && r.ptr == (uintptr_t)p) r.t_free = now_us();      // unless the ring has moved on
+        live.erase(it);
         return;
     }
-    const uint64_t i = g_n_blocks.fetch_add(1, std::memory_order_acq_rel);
+    const uint64_t i = g_n_blocks.load(std::memory_order_relaxed);
     BlockRec &r = g_blocks[i % N_BLOCKS];
     r.ptr = (uintptr_t)p; r.size = n; r.tag = tag; r.t_alloc = now_us(); r.t_free = 0;
+    g_n_blocks.store(i + 1, std::memory_order_release);
+    live[(uintptr_t)p] = i;
 }
 
 void zk_fault_register_ctx(zk_ctx *c) {
