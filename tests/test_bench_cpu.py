@@ -51,3 +51,22 @@ def test_roofline_inputs_are_committed():
     assert 1e11 < peak < 2e12, (peak, src)
     assert bench.algorithmic_bytes_per_launch("poseidon_leaf_hash_c93", 20, 1) == 8 * (1 << 21) * 93 + 32 * (1 << 21)
     assert bench.algorithmic_bytes_per_launch("transcript", 20, 1) is None
+
+
+def test_a_failing_transaction_child_becomes_an_error_record_not_a_lost_line(capfd):
+    """The default line's transaction record is measured by a child process (bench.prove_root_record): whatever happens to that child --
+    here it cannot create a context (no GPU), on a GPU box it might fault or hang -- the parent gets an error record, with the child's
+    stderr passed on, and goes on to print its line."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("the child would succeed on a GPU box")
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = bench.prove_root_record(types.SimpleNamespace(prepare="never"), timeout_s=240)
+    assert set(rec) >= {"error", "gpu_memory_fault", "command"} and "exited with code" in rec["error"] and rec["gpu_memory_fault"] is False
+    assert "--workload prove_root" in rec["command"]
+    assert capfd.readouterr().err.strip(), "the child's stderr was not passed on"
