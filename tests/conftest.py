@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that stops making progress (a wait on the device that never returns) must end the run, not sit until the harness kills the
+    box: ten minutes per test through pytest-timeout's watchdog thread (stack dump, then the process exits) when the plugin is there."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
+            it.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 def field_rand(rng, shape):
     """uniform canonical field elements"""
     a = rng.integers(0, 1 << 64, size=shape, dtype=np.uint64)
