@@ -83,6 +83,14 @@ def check_statement(stmt, macros):
     scc = sorted({o for o in ops if o.startswith("s_") and o not in NO_SCC})
     if scc and "scc" not in clobbers:
         problems.append('%s write(s) SCC without an "scc" clobber' % ", ".join(scc))
+    # registers named outright (not through an operand) must be declared as well
+    named = set()
+    for kind, lo, hi in re.findall(r"(?<![\w%\[])([sv])\[(\d+):(\d+)\]", template):
+        named.update("%s%d" % (kind, i) for i in range(int(lo), int(hi) + 1))
+    named.update("%s%s" % (k, n) for k, n in re.findall(r"(?<![\w%\[.])([sv])(\d+)\b(?!\s*:)", template))
+    missing = sorted(named - clobbers, key=lambda r: (r[0], int(r[1:])))
+    if missing:
+        problems.append("names %s without declaring %s" % (", ".join(missing[:6]) + (" ..." if len(missing) > 6 else ""), "them" if len(missing) > 1 else "it"))
     for reg in ("exec", "m0"):
         if re.search(r"\b(s_\w+|v_cmpx\w*|v_readfirstlane\w*)\s+%s\b" % reg, template) and reg not in clobbers:
             problems.append("writes %s without declaring it" % reg)
