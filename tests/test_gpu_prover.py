@@ -3,7 +3,7 @@ and the oracle's independent verifier accepts them."""
 import numpy as np
 import pytest
 
-from conftest import P
+from conftest import P, field_rand
 
 pytestmark = pytest.mark.gpu
 
@@ -493,5 +493,44 @@ def test_host_side_challenger_gives_the_same_proofs(zk, orc):
         ch.observe(big); och.observe(big)
         assert (ch.get(5) == och.get(5)).all() and (ch.compact() == och.compact()).all()
         c2.set_host_transcript(False)
+    finally:
+        c2.close()
+
+
+@pytest.mark.gpu
+def test_every_block_across_a_4gib_boundary_gives_the_same_proofs(zk, orc, monkeypatch):
+    """The layout behind the GPU memory faults of rounds 1-4: a device block that straddles a 4 GiB boundary, read or
+    written behind the boundary by a kernel whose pointer arithmetic had lost its carry (an asm block overwrote SCC between s_add_u32 and
+    s_addc_u32).  ZK_ALLOC_EFENCE=2 places EVERY block of a context across such a boundary: transforms, commitments, a STARK unit with
+    lookups through the build-time constraint kernel, a unit through the interpreter, and a Plonk proof with the compiled recursion gate
+    program must still be the oracle's, bit for bit.  (A regression here is a GPU memory fault, not a wrong word: the library's handler
+    reports it and ends the process.)"""
+    import eth_tx_proof_amd as E
+    from eth_tx_proof_amd import air, plonk
+    monkeypatch.setenv("ZK_ALLOC_EFENCE", "2")
+    c2 = zk.Context(0)
+    try:
+        rng = np.random.default_rng(44)
+        for log_n, ncols in ((12, 5), (16, 9), (18, 3)):              # one pass, two passes, coset-merged and plain LDE shapes
+            vals = field_rand(rng, (ncols, 1 << log_n))
+            assert (c2.ntt(vals) == orc.fft(vals)).all() and (c2.ntt(vals, inverse=True) == orc.fft(vals, inverse=True)).all()
+            b, o = c2.batch_from_values(vals, rate_bits=1, cap_height=4), orc.Batch(vals, rate_bits=1, cap_height=4)
+            assert (b.cap == o.cap).all() and (b.digests() == o.digests).all()
+            b.free()
+        cfg = E.standard_fast_config()
+        for w, h, lg, seed in ((93, 19, 12, 5), (21, 5, 10, 6)):      # 93 x 19 helpers: a kernel built with the library
+            prog = air.cpu_like_air(w, h)
+            tr, pub = orc.synth_trace(w, lg, seed)
+            rc, ref = orc.prove(cfg, [(prog, lg, tr, pub)])
+            assert rc == 0 and (zk.prove_tables(c2, cfg, [(prog, lg, tr, pub)]) == ref).all()
+        rcfg = E.standard_recursion_config()
+        circ, wires = plonk.synthetic_circuit(degree_bits=12, seed=3)
+        pubs = np.array([12, 3, 99], dtype=np.uint64)
+        ost, st = orc.PlonkState(rcfg, circ), zk.PlonkState(c2, rcfg, circ)
+        try:
+            rc, ref = orc.prove_plonk(ost, wires, pubs)
+            assert rc == 0 and (zk.prove_plonk(st, wires, pubs, ctx=c2) == ref).all()
+        finally:
+            st.free()
     finally:
         c2.close()
