@@ -351,7 +351,7 @@ int32_t zk_ntt_lde(zk_ctx *ctx, const u64 *coeffs, size_t in_stride, u64 *lde, s
     int w[4], np; digit_widths(log_n, w, &np);
     static const int merge = getenv("ZK_NTT_COSET_MERGE") ? atoi(getenv("ZK_NTT_COSET_MERGE")) : 1;
     bool merged = merge && rate_bits >= 1 && log_n >= 4 && log_n <= 20 && np <= 2 && !getenv("ZK_NTT_SLOW") &&
-                  (n >> 13) * (size_t)n_cols < 4096;                   // a launch per coset already fills the chip beyond this
+                  ((n >> 13) * (size_t)n_cols < 4096 || merge >= 2);   // a launch per coset already fills the chip beyond this (2: merge anyway, experiment)
     if (merged && np == 2 && w[1] < 13 - w[0]) merged = false;          // the TILE pass would not take the register-radix kernel
     if (merged) {
         u64 *mid = nullptr;
