@@ -4,9 +4,9 @@
 //
 // One wave = 64 permutations in "pair layout": lane (n = l&31, h = l>>5) holds words 6h..6h+5 of permutations n and 32+n.
 //   * s-boxes: 12 per lane per full round, exactly as in the one-thread-per-permutation kernel (psd::core products);
-//   * MDS (+ next round constants): 18 matrix-core instructions per wave and layer, operands straight from the state
-//     registers (bytes XOR 0x80), results recombined from eight 25-bit limb sums per word with 13 vector instructions --
-//     against 24 multiply-adds + 5 per word on the vector ALU;
+//   * MDS (+ next round constants): 8 matrix-core instructions per wave and layer (two byte planes each: the MDS constants are
+//     single digits, poseidon_mfma_tables.h), operands from the state registers (bytes XOR 0x80, one v_perm_b32 per two words and
+//     plane pair), results recombined from eight 25-bit limb sums per word -- against 24 multiply-adds + 5 per word on the vector ALU;
 //   * the 22 partial rounds: the s-box chain x_{q+1} = E[q] + sum_{j<=q} PR_D[q][j] y_j runs one permutation per lane in blocks
 //     of four rounds; what a block needs from the state (E) and from all earlier blocks is one matrix product per block, the exit
 //     map another, and only the in-block feedback (31 products per permutation) runs on the vector ALU (two v_permlane32_swap
@@ -19,12 +19,21 @@
 
 typedef int psdm_v4i __attribute__((ext_vector_type(4)));
 typedef int psdm_v16i __attribute__((ext_vector_type(16)));
+// PSDM_EXPERIMENT_NO_MFMA (tools/psdm_test.hip only; the results are wrong on purpose): every matrix instruction replaced by one vector
+// instruction that keeps its operands alive -- what the kernel would cost if its linear layers were free, i.e. the most any change to the
+// matrix-core side (fewer k-steps, block-sparse operands, lower power) could ever give.
+#ifdef PSDM_EXPERIMENT_NO_MFMA
+__device__ __forceinline__ psdm_v16i psdm_no_mfma(psdm_v4i a, psdm_v4i b, psdm_v16i c) { c[0] += a[0] ^ b[0]; return c; }
+#define PSDM_MFMA(a, b, c) psdm_no_mfma((a), (b), (c))
+#else
+#define PSDM_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8((a), (b), (c), 0, 0, 0)
+#endif
 
-// LDS image per workgroup, in 16-byte fragments: the MDS operand tiles (one per (tile, k-step, lane)), then the accumulator
-// starts Cin_mds | Cin_F | Cin_G2 (four fragments per (.., lane half)) -- 13 KiB
-#define PSDM_LDS_A 576
+// LDS image per workgroup, in 16-byte fragments: the MDS operand (one fragment per lane), then the accumulator
+// starts Cin_mds | Cin_F | Cin_G2 (four fragments per (.., lane half)) -- 6 KiB
+#define PSDM_LDS_A 64
 #define PSDM_LDS_CMDS (PSDM_LDS_A)
-#define PSDM_LDS_CF (PSDM_LDS_CMDS + 8 * 3 * 2 * 4)
+#define PSDM_LDS_CF (PSDM_LDS_CMDS + 8 * 4 * 2 * 4)
 #define PSDM_LDS_CG2 (PSDM_LDS_CF + 6 * 2 * 4)
 #define PSDM_LDS_V4 (PSDM_LDS_CG2 + 3 * 2 * 4)
 
@@ -35,7 +44,7 @@ __device__ __forceinline__ psdm_v4i ld4(const void *p);
 // used 8 x 18 times per permutation: reading it from LDS costs no vector registers (36 if held) and no L1 traffic; the accumulator
 // starts (the same 64 bytes for all 32 lanes of a half: an LDS broadcast) were 132 of the ~200 16-byte global loads per permutation.
 __device__ __forceinline__ void lds_fill(const PsdmTables *T, psdm_v4i *sh) {
-    const psdm_v4i *a = (const psdm_v4i *)&T->A_mds[0][0][0][0], *c0 = (const psdm_v4i *)&T->Cin_mds[0][0][0][0],
+    const psdm_v4i *a = (const psdm_v4i *)&T->A_mds[0][0], *c0 = (const psdm_v4i *)&T->Cin_mds[0][0][0][0],
                    *c1 = (const psdm_v4i *)&T->Cin_F[0][0][0], *c2 = (const psdm_v4i *)&T->Cin_G2[0][0][0];
     for (u32 i = threadIdx.x; i < PSDM_LDS_A; i += blockDim.x) sh[i] = a[i];
     for (u32 i = threadIdx.x; i < PSDM_LDS_CF - PSDM_LDS_CMDS; i += blockDim.x) sh[PSDM_LDS_CMDS + i] = c0[i];
@@ -99,6 +108,18 @@ __device__ __forceinline__ u64 recombine(const rk &K, u32 u0, u32 u1, u32 u2, u3
     w = ((u64)rh << 32) | rl;
     return gl_madd1(m, w);
 }
+// the same from the four limb PAIRS t_P = u_2P + 2^8 u_(2P+1) (each below 2^32): what an MDS layer keeps of a tile's accumulator
+__device__ __forceinline__ u64 recombine_pairs(const rk &K, u32 t0, u32 t1, u32 t2, u32 t3) {
+    const u64 AL = (u64)t1 * K.k16 + t0, AH = (u64)t3 * K.k16 + t2;
+    const u64 r = (u64)(u32)(AH >> 32) * K.keps + AL;
+    u32 rl = (u32)r, rh = (u32)(r >> 32), ahl = (u32)AH, m; u64 w;
+    asm("v_add_co_u32 %[rh], vcc, %[rh], %[a]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %[m], 0, -1, vcc\n\t"
+        : [rh] "+v"(rh), [m] "=&v"(m) : [a] "v"(ahl) : "vcc");
+    w = ((u64)rh << 32) | rl;
+    return gl_madd1(m, w);
+}
 __device__ __forceinline__ void recombine2(const rk &K, const psdm_v16i &acc, u64 &o0, u64 &o1) {
     o0 = recombine(K, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
     o1 = recombine(K, acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
@@ -123,25 +144,44 @@ template <bool EXACT, int NC = 2> struct perm {
 
     __device__ __forceinline__ void init(const PsdmTables *tab, u32 lane_, const psdm_v4i *lds) { T = (const __attribute__((address_space(1))) PsdmTables *)tab; lane = lane_; pc.fl = 0; K.init(); Alds = (psdm_lds_ptr)lds; }
 
-    // s <- MDS * s + constants of layer `layer`
+    // s <- MDS * s + constants of layer `layer`.  Two byte planes (= one halfword of every state word) per instruction: operand bytes
+    // j < 12 of lane (n, h) are the bytes of halfword P of its six words (XOR 0x80), result registers 2i, 2i+1 the limbs 2P, 2P+1 of its
+    // word i (poseidon_mfma_tables.h); of each accumulator only the six limb pairs are kept until the four tiles are done.
     __device__ __forceinline__ void mds(u64 (&s)[NC][6], int layer) {
-        psdm_v4i b[NC][3];
+        u32 x[NC][2][6];
 #pragma unroll
         for (int c = 0; c < NC; c++)
 #pragma unroll
-            for (int k = 0; k < 3; k++) b[c][k] = bfrag(s[c][2 * k], s[c][2 * k + 1]);
+            for (int i = 0; i < 6; i++) { x[c][0][i] = (u32)s[c][i] ^ 0x80808080u; x[c][1][i] = (u32)(s[c][i] >> 32) ^ 0x80808080u; }
+        const psdm_v4i a = Alds[lane];
+        u32 t[NC][4][6];
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const psdm_v16i cin = ld16l(Alds + PSDM_LDS_CMDS + ((layer * 3 + t) * 2 + (lane >> 5)) * 4);
-            const psdm_v4i a0 = Alds[(3 * t + 0) * 64 + lane], a1 = Alds[(3 * t + 1) * 64 + lane], a2 = Alds[(3 * t + 2) * 64 + lane];
+        for (int P = 0; P < 4; P++) {
+            const psdm_v16i cin = ld16l(Alds + PSDM_LDS_CMDS + ((layer * 4 + P) * 2 + (lane >> 5)) * 4);
+            const u32 sel = (P & 1) ? 0x07060302u : 0x05040100u;           // v_perm_b32: halfword (P & 1) of two dwords
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                psdm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b[c][0], cin, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b[c][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b[c][2], acc, 0, 0, 0);
-                recombine2(K, acc, s[c][2 * t], s[c][2 * t + 1]);
+                psdm_v4i b;
+                b[0] = (int)__builtin_amdgcn_perm(x[c][P >> 1][1], x[c][P >> 1][0], sel);
+                b[1] = (int)__builtin_amdgcn_perm(x[c][P >> 1][3], x[c][P >> 1][2], sel);
+                b[2] = (int)__builtin_amdgcn_perm(x[c][P >> 1][5], x[c][P >> 1][4], sel);
+                b[3] = 0;
+                const psdm_v16i acc = PSDM_MFMA(a, b, cin);
+#pragma unroll
+                for (int i = 0; i < 6; i++) t[c][P][i] = ((u32)acc[2 * i + 1] << 8) + (u32)acc[2 * i];
+                // Registers 12..15 of the result are padding rows and nothing reads them -- which makes them free registers for the compiler
+                // from the instruction AFTER the matrix instruction on, while the hardware writes all sixteen when it finishes, 64 cycles
+                // later.  hipcc pads its own instructions against that (write after write on an in-flight result), but the vector
+                // instructions inside the inline-asm blocks of the s-boxes are invisible to its hazard recognizer: a value they had just
+                // put into one of the four was overwritten (the second permutation of every pair came out wrong whenever register
+                // pressure made the allocator take those registers).  The whole result stays live until its limbs have been read.
+                asm volatile("" : : "v"(acc));
             }
         }
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int i = 0; i < 6; i++) s[c][i] = recombine_pairs(K, t[c][0][i], t[c][1][i], t[c][2][i], t[c][3][i]);
     }
     __device__ __forceinline__ void full_rounds(u64 (&s)[NC][6], int layer0) {
 #pragma unroll 1
@@ -181,8 +221,8 @@ template <bool EXACT, int NC = 2> struct perm {
 #pragma unroll
                 for (int k = 0; k < 3 + b; k++) {
                     const psdm_v4i a = ld4(&T->A_F[b][k][lane][0]);
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0, 0, 0, 0);
-                    if (NC == 2) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1, 0, 0, 0);
+                    acc0 = PSDM_MFMA(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0);
+                    if (NC == 2) acc1 = PSDM_MFMA(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1);
                 }
                 u64 f0[2], f1[2];
                 recombine2(K, acc0, f0[0], f0[1]);
@@ -227,8 +267,8 @@ template <bool EXACT, int NC = 2> struct perm {
 #pragma unroll
             for (int k = 0; k < 9; k++) {
                 const psdm_v4i a = ld4(&T->A_G2[t][k][lane][0]);
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0, 0, 0, 0);
-                if (NC == 2) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1, 0, 0, 0);
+                acc0 = PSDM_MFMA(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0);
+                if (NC == 2) acc1 = PSDM_MFMA(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1);
             }
             recombine2(K, acc0, s[0][2 * t], s[0][2 * t + 1]);
             if (NC == 2) recombine2(K, acc1, s[NC - 1][2 * t], s[NC - 1][2 * t + 1]);

@@ -26,9 +26,17 @@
 #include <vector>
 #include "gl64.cuh"
 
+// The MDS layers are a special case: their constants are below 2^7, so M * 2^(8b) has ONE non-zero digit, at position b -- output limb a
+// depends on byte a of the twelve state words and on nothing else, the 96 x 96 operand of the general scheme is block-diagonal by byte
+// plane and seven eighths of its products multiply zeros.  An MDS layer therefore runs TWO planes per instruction (round 4: the matrix
+// pipe is NOT hidden behind the vector ALU on this chip -- an i8 32x32x32 instruction holds the SIMD for its 64 cycles, removing all of
+// them makes the leaf hash 28 % faster, DESIGN.md section 5 -- so instruction count on this side matters):
+//   tile P = 0..3 covers byte planes 2P, 2P+1 = halfword P of every word;  K index (lane half h, byte j < 12) = byte (j & 1) of halfword
+//   P of word 6h + (j >> 1) (j = 12..15: padding);  output row (lane half h', register r < 12) = limb 2P + (r & 1) of word 6h' + (r >> 1).
+// One operand fragment serves all four tiles and all eight layers; 8 instructions per layer and wave instead of 18.
 struct PsdmTables {
-    int8_t A_mds[3][3][64][16];
-    int32_t Cin_mds[8][3][2][16];      // [layer][tile][lane half][register]; layer L: next-layer constants RC[L+1] (L<3), PR_FIRST (3), RC[27+L-4] (4..6), none (7)
+    int8_t A_mds[64][16];
+    int32_t Cin_mds[8][4][2][16];      // [layer][plane pair][lane half][register]; layer L: next-layer constants RC[L+1] (L<3), PR_FIRST (3), RC[27+L-4] (4..6), none (7)
     // s-box chain of the partial rounds in blocks of four rounds: tile b gives, for rows q = 4b .. 4b+3 (lane half h', slot i:
     // q = 4b + 2h' + i), F[q] = E[q] + sum_{j < 4b} PR_D[q][j] y_j with E[q] = <vhat_q, PR_INIT * s[1..]>.
     // K-steps: 0..2 = the 12 state words, 3 + b' = the four s-box outputs y_{4b'} .. y_{4b'+3} of block b' < b (lane half h, word
@@ -122,20 +130,54 @@ static inline u64 mds_entry(int W, int wi) {
     return C[((wi - W) % 12 + 12) % 12] + ((W == 0 && wi == 0) ? 8 : 0);
 }
 
+// the constants that MDS layer L adds: those of the layer that follows it
+static inline const u64 *mds_next_constants(int L) {
+    if (L < 3) return PSD_RC + 12 * (L + 1);
+    if (L == 3) return PSD_PR_FIRST;
+    if (L < 7) return PSD_RC + 12 * (26 + (L - 4) + 1);
+    return nullptr;
+}
+// MDS layers, two byte planes per instruction (see PsdmTables)
+static void fill_mds(PsdmTables &t) {
+    const u64 ONES = 0x0101010101010101ULL % GL_P;
+    const u64 offc = gl_mul(((u64)1 << OFF_LOG) % GL_P, ONES);
+    long rowsum[32];
+    for (int m = 0; m < 32; m++) rowsum[m] = 0;
+    for (int l = 0; l < 64; l++) {
+        const int m = l & 31, h = l >> 5;
+        const int hp = (m >> 2) & 1, u = 4 * (m >> 3) + (m & 3);           // row m = register u of lane half hp (rho_of)
+        for (int j = 0; j < 16; j++) {
+            int8_t v = 0;
+            if (u < 12 && j < 12 && (u & 1) == (j & 1)) {
+                const u64 c = mds_entry(6 * hp + (u >> 1), 6 * h + (j >> 1));
+                if (c >= 128) abort();                                      // one digit, as a signed byte
+                v = (int8_t)c;
+            }
+            t.A_mds[l][j] = v;
+            rowsum[m] += v;
+        }
+    }
+    for (int L = 0; L < 8; L++) {
+        const u64 *nxt = mds_next_constants(L);
+        for (int P = 0; P < 4; P++)
+            for (int hh = 0; hh < 2; hh++)
+                for (int r = 0; r < 16; r++) {
+                    int32_t v = (int32_t)1 << OFF_LOG;
+                    if (r < 12) {
+                        const int W = 6 * hh + (r >> 1), limb = 2 * P + (r & 1);
+                        const u64 kk = gl_sub((nxt ? nxt[W] : (u64)0) % GL_P, offc);
+                        v += (int32_t)(128 * rowsum[rho_of(32 * hh, r)]) + (int32_t)((kk >> (8 * limb)) & 0xFF);
+                    }
+                    t.Cin_mds[L][P][hh][r] = v;
+                }
+    }
+}
+
 static void build(PsdmTables &t) {
     memset(&t, 0, sizeof t);
-    auto state_kword = [](int ks, int h, int wsel) { return ks < 3 ? 6 * h + 2 * ks + wsel : -1; };
     auto word_out = [](int hp, int slot) { return slot < 6 ? 6 * hp + slot : -1; };
     // ---- MDS (+ the constants of the layer that follows)
-    for (int L = 0; L < 8; L++) {
-        const u64 *nxt = nullptr;
-        if (L < 3) nxt = PSD_RC + 12 * (L + 1);
-        else if (L == 3) nxt = PSD_PR_FIRST;
-        else if (L < 7) nxt = PSD_RC + 12 * (26 + (L - 4) + 1);
-        static int8_t Atmp[3][3][64][16];
-        fill(3, 3, L == 0 ? &t.A_mds[0][0][0][0] : &Atmp[0][0][0][0], &t.Cin_mds[L][0][0][0], word_out, state_kword,
-             [](int W, int wi) { return mds_entry(W, wi); }, [&](int W) { return nxt ? nxt[W] : (u64)0; });
-    }
+    fill_mds(t);
     // ---- G1: E[e] = sum_j (sum_i vhat_e[i] * PR_INIT[11 i + j]) * s[1 + j]
     static u64 G1[22][12];
     for (int e = 0; e < 22; e++) {

@@ -39,6 +39,48 @@ static void emulate(int n_tiles, int n_ksteps, const int8_t *A, const int32_t *C
         }
 }
 
+// one column through the four two-plane instructions of an MDS layer (PsdmTables: K index (h, j < 12) = byte j & 1 of halfword P of word
+// 6h + (j >> 1); register r < 12 of lane half h' = limb 2P + (r & 1) of word 6h' + (r >> 1)); returns the twelve words mod p
+static void emulate_mds(const PsdmTables &t, int L, const u64 s[12], u64 out[12]) {
+    long limb[12][8];
+    for (int P = 0; P < 4; P++)
+        for (int hp = 0; hp < 2; hp++) {
+            long acc[16];
+            for (int r = 0; r < 16; r++) acc[r] = t.Cin_mds[L][P][hp][r];
+            for (int h = 0; h < 2; h++)
+                for (int j = 0; j < 16; j++) {
+                    int sb = 0;
+                    if (j < 12) sb = (int)(int8_t)(((s[6 * h + (j >> 1)] >> (16 * P + 8 * (j & 1))) & 0xFF) ^ 0x80);
+                    for (int r = 0; r < 16; r++) acc[r] += (long)t.A_mds[32 * h + rho_of(32 * hp, r)][j] * sb;
+                }
+            for (int r = 0; r < 12; r++) {
+                if (acc[r] < 0 || acc[r] >= (1L << 24) - (1L << 16)) { printf("MDS accumulator out of range\n"); exit(1); }
+                limb[6 * hp + (r >> 1)][2 * P + (r & 1)] = acc[r];
+            }
+        }
+    for (int W = 0; W < 12; W++) {
+        u64 v = 0;
+        for (int a = 7; a >= 0; a--) v = gl_add(gl_mul(v, 256), (u64)limb[W][a] % GL_P);
+        out[W] = v;
+    }
+}
+static int worst_case_mds(const PsdmTables &t) {
+    long gmin = 1L << 40, gmax = -(1L << 40);
+    for (int L = 0; L < 8; L++) for (int P = 0; P < 4; P++) for (int hp = 0; hp < 2; hp++) for (int r = 0; r < 16; r++) {
+        long lo = 0, hi = 0;
+        for (int h = 0; h < 2; h++) for (int j = 0; j < 16; j++) {
+            const long d = t.A_mds[32 * h + rho_of(32 * hp, r)][j];
+            if (d > 0) { hi += 127 * d; lo -= 128 * d; } else { hi -= 128 * d; lo += 127 * d; }
+        }
+        const long c = t.Cin_mds[L][P][hp][r];
+        if (c + lo < gmin) gmin = c + lo;
+        if (c + hi > gmax) gmax = c + hi;
+    }
+    const bool ok = gmin >= 0 && gmax < (1L << 24) - (1L << 16);
+    if (!ok) printf("MDS: limb sums can reach [%ld, %ld], outside [0, 2^24 - 2^16)\n", gmin, gmax);
+    return ok ? 0 : 1;
+}
+
 // worst case over EVERY operand (each signed byte at whichever end of [-128, 127] hurts most): all limb sums must stay inside
 // [0, 2^24 - 2^16), the range the 32-bit limb pairing of psdm::recombine relies on
 static int worst_case(const char *name, int n_tiles, int n_ksteps, const int8_t *A, const int32_t *Cin) {
@@ -67,7 +109,7 @@ int main() {
     static PsdmTables t; build(t);
     {
         int wc = 0;
-        for (int L = 0; L < 8; L++) wc += worst_case("MDS", 3, 3, &t.A_mds[0][0][0][0], &t.Cin_mds[L][0][0][0]);
+        wc += worst_case_mds(t);
         for (int b = 0; b < 6; b++) wc += worst_case("F", 1, 3 + b, &t.A_F[b][0][0][0], &t.Cin_F[b][0][0]);
         wc += worst_case("G2", 3, 9, &t.A_G2[0][0][0][0], &t.Cin_G2[0][0][0]);
         if (wc) { printf("matrix-core Poseidon tables: limb range FAIL\n"); return 1; }
@@ -80,13 +122,13 @@ int main() {
         for (int ks = 0; ks < 3; ks++) for (int h = 0; h < 2; h++) for (int w = 0; w < 2; w++) kw[ks][h][w] = s[6 * h + 2 * ks + w];
         // ---- MDS layers
         for (int L = 0; L < 8; L++) {
-            u64 out[2][12];
-            emulate(3, 3, &t.A_mds[0][0][0][0], &t.Cin_mds[L][0][0][0], kw, out);
+            u64 out[12];
+            emulate_mds(t, L, s, out);
             const u64 *nxt = L < 3 ? PSD_RC + 12 * (L + 1) : L == 3 ? PSD_PR_FIRST : L < 7 ? PSD_RC + 12 * (27 + L - 4) : nullptr;
             for (int W = 0; W < 12; W++) {
                 u64 want = nxt ? nxt[W] : 0;
                 for (int wi = 0; wi < 12; wi++) want = gl_add(want, gl_mul(mds_entry(W, wi), s[wi] % GL_P));
-                if (gl_canon(out[W / 6][W % 6]) != want) { if (bad++ < 5) printf("MDS layer %d word %d mismatch\n", L, W); }
+                if (gl_canon(out[W]) != want) { if (bad++ < 5) printf("MDS layer %d word %d mismatch\n", L, W); }
             }
         }
         // ---- partial rounds, straight from the sparse form (s = state with PR_FIRST already added)

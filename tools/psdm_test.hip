@@ -63,6 +63,35 @@ template <int STAGE> __global__ __launch_bounds__(256) void k_stage_ref(u64 *sta
     if (STAGE == 2) { pc.partial_rounds(s); for (int k = 0; k < 12; k++) s[k] = psd::wadd_c(s[k], PSD_RC[12 * 26 + k]); }
     for (int k = 0; k < 12; k++) states[12 * i + k] = gl_canon(s[k]);
 }
+// the Merkle-level shape of the product kernels (poseidon_kernels.hip two_to_one_pair): eight words from the children, four zeros
+#ifndef KLB
+#define KLB 3
+#endif
+template <bool EXACT> __global__ __launch_bounds__(256, KLB) void k_level(const PsdmTables *T, const u64 *child, u64 *parent, u64 *flags) {
+    const u32 lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const size_t parent0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(size_t)63;
+    __shared__ psdm_v4i shA[PSDM_LDS_V4];
+    psdm::lds_fill(T, shA); __syncthreads();
+    psdm::perm<EXACT> pm; pm.init(T, lane, shA);
+    u64 s[2][6];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const u64 *p = child + 8 * (parent0 + 32 * c + n);
+        if (h == 0) {
+            const ulonglong2 a = ((const ulonglong2 *)p)[0], b = ((const ulonglong2 *)p)[1], d = ((const ulonglong2 *)p)[2];
+            s[c][0] = a.x; s[c][1] = a.y; s[c][2] = b.x; s[c][3] = b.y; s[c][4] = d.x; s[c][5] = d.y;
+        } else {
+            const ulonglong2 e = ((const ulonglong2 *)p)[3];
+            s[c][0] = e.x; s[c][1] = e.y; s[c][2] = 0; s[c][3] = 0; s[c][4] = 0; s[c][5] = 0;
+        }
+    }
+    pm.run(s);
+    if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) { u64 *o = parent + 4 * (parent0 + 32 * c + lane); o[0] = s[c][0]; o[1] = s[c][1]; o[2] = s[c][2]; o[3] = s[c][3]; }
+    }
+    if (flags) flags[parent0 + lane] = pm.pc.fl;
+}
 #ifndef LB
 #define LB 2
 #endif
@@ -79,7 +108,9 @@ __global__ __launch_bounds__(256, LB) void k_time(const PsdmTables *T, u64 *out,
     for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int i = 0; i < 6; i++) s[c][i] = (seed + threadIdx.x * 12 + i + 6 * c + blockIdx.x * 4096) * 0x9E3779B97F4A7C15ULL % GL_P;
+    const u64 c0 = clock64(), w0 = wall_clock64();          // shader cycles and the constant-rate counter: their ratio is the clock the kernel was given
     for (int r = 0; r < REPS; r++) pm.run(s);
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { out[8] = clock64() - c0; out[9] = wall_clock64() - w0; }
     u64 x = pm.pc.fl;
 #pragma unroll
     for (int c = 0; c < 2; c++)
@@ -132,6 +163,25 @@ int main() {
         printf("matrix-core permutation (%s products) vs psd::permute on %zu states: %s (%zu word mismatches, %zu flagged lanes)\n", exact ? "exact" : "fast", P, bad ? "FAIL" : "OK", bad, flagged);
         rc |= bad != 0;
     }
+    {   // Merkle-level shape: P parents from 2P random canonical child digests
+        std::vector<u64> ch(P * 8), st(P * 12), got(P * 4);
+        for (size_t i = 0; i < P * 8; i++) ch[i] = splitmix(z) % GL_P;
+        for (size_t i = 0; i < P; i++) for (int k = 0; k < 12; k++) st[12 * i + k] = k < 8 ? ch[8 * i + k] : 0;
+        u64 *dC, *dP; hipMalloc(&dC, P * 64); hipMalloc(&dP, P * 32);
+        hipMemcpy(dC, ch.data(), P * 64, hipMemcpyHostToDevice); hipMemcpy(dB, st.data(), P * 96, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_level<false>, dim3(P / 256), dim3(256), 0, 0, dT, dC, dP, dF);
+        hipLaunchKernelGGL(k_ref, dim3(P / 256), dim3(256), 0, 0, dB);
+        hipDeviceSynchronize();
+        hipMemcpy(got.data(), dP, P * 32, hipMemcpyDeviceToHost); hipMemcpy(b.data(), dB, P * 96, hipMemcpyDeviceToHost); hipMemcpy(fl.data(), dF, P * 8, hipMemcpyDeviceToHost);
+        size_t bad = 0; size_t by_lane[64] = {0};
+        for (size_t i = 0; i < P; i++) for (int k = 0; k < 4; k++) if (got[4 * i + k] != b[12 * i + k] && !fl[i & ~(size_t)63]) {
+            if (bad < 4) printf("  level parent %zu word %d: got %016llx want %016llx\n", i, k, (unsigned long long)got[4 * i + k], (unsigned long long)b[12 * i + k]);
+            bad++; by_lane[i & 63]++;
+        }
+        printf("Merkle-level shape (two children + zero capacity) vs psd::permute on %zu parents: %s (%zu word mismatches)\n", P, bad ? "FAIL" : "OK", bad);
+        if (bad) { printf("  mismatches by position in the wave:"); for (int k = 0; k < 64; k++) printf(" %zu", by_lane[k]); printf("\n"); }
+        rc |= bad != 0;
+    }
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -145,7 +195,10 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         double perms = (double)blocks * 256 * REPS * rounds;
-        printf("  blocks %5d (%d waves/SIMD launched): %8.3f ms/launch  %.3e perms/s\n", blocks, w, ms / rounds, perms / (ms * 1e-3));
+        u64 ck[2] = {0, 1}; hipMemcpy(ck, dA + 8, 16, hipMemcpyDeviceToHost);
+        int wrate = 0; hipDeviceGetAttribute(&wrate, hipDeviceAttributeWallClockRate, 0);          // kHz
+        printf("  blocks %5d (%d waves/SIMD launched): %8.3f ms/launch  %.3e perms/s   shader clock under the kernel %.2f GHz (%llu cycles of one wave for %d permutations)\n", blocks, w,
+               ms / rounds, perms / (ms * 1e-3), (double)ck[0] / (double)ck[1] * wrate * 1e-6, (unsigned long long)ck[0], REPS);
     }
     return rc;
 }
