@@ -22,6 +22,14 @@ typedef int psdm_v16i __attribute__((ext_vector_type(16)));
 // PSDM_EXPERIMENT_NO_MFMA (tools/psdm_test.hip only; the results are wrong on purpose): every matrix instruction replaced by one vector
 // instruction that keeps its operands alive -- what the kernel would cost if its linear layers were free, i.e. the most any change to the
 // matrix-core side (fewer k-steps, block-sparse operands, lower power) could ever give.
+// PSDM_EXPERIMENT_A_HOT (tools/psdm_test.hip only, wrong results on purpose): every operand fragment of the partial rounds' products read
+// from ONE address per lane, i.e. always a first-level cache hit -- what the 60 KiB of F / G2 operands cost by not fitting that cache
+// (5-7 % of the kernel at saturation; moving them into LDS with one 768-thread workgroup per CU was measured and is slower)
+#ifdef PSDM_EXPERIMENT_A_HOT
+#define PSDM_AHOT(i) 0
+#else
+#define PSDM_AHOT(i) (i)
+#endif
 #ifdef PSDM_EXPERIMENT_NO_MFMA
 __device__ __forceinline__ psdm_v16i psdm_no_mfma(psdm_v4i a, psdm_v4i b, psdm_v16i c) { c[0] += a[0] ^ b[0]; return c; }
 #define PSDM_MFMA(a, b, c) psdm_no_mfma((a), (b), (c))
@@ -220,7 +228,7 @@ template <bool EXACT, int NC = 2> struct perm {
                 psdm_v16i acc0 = cin, acc1 = cin;
 #pragma unroll
                 for (int k = 0; k < 3 + b; k++) {
-                    const psdm_v4i a = ld4(&T->A_F[b][k][lane][0]);
+                    const psdm_v4i a = ld4(&T->A_F[PSDM_AHOT(b)][PSDM_AHOT(k)][lane][0]);
                     acc0 = PSDM_MFMA(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0);
                     if (NC == 2) acc1 = PSDM_MFMA(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1);
                 }
@@ -266,7 +274,7 @@ template <bool EXACT, int NC = 2> struct perm {
             psdm_v16i acc0 = cin, acc1 = cin;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
-                const psdm_v4i a = ld4(&T->A_G2[t][k][lane][0]);
+                const psdm_v4i a = ld4(&T->A_G2[PSDM_AHOT(t)][PSDM_AHOT(k)][lane][0]);
                 acc0 = PSDM_MFMA(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0);
                 if (NC == 2) acc1 = PSDM_MFMA(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1);
             }
