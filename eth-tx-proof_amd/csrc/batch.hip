@@ -100,6 +100,9 @@ struct EvalMulti {
     const u64 *coeffs[ZK_EVAL_MAX_JOBS]; size_t stride[ZK_EVAL_MAX_JOBS];
     u64 *out[ZK_EVAL_MAX_JOBS];
     const u64 *points[ZK_EVAL_MAX_JOBS];
+    // jobs that read the SAME coefficient columns at two points (the openings at zeta and at g * zeta) are evaluated in one pass over the
+    // columns: the launch covers the columns of the primary jobs only, pair[j] = the job whose sums the same blocks produce as well
+    u32 n_launch_jobs, launch_job[ZK_EVAL_MAX_JOBS], lcol0[ZK_EVAL_MAX_JOBS + 1], pair[ZK_EVAL_MAX_JOBS];
 };
 __global__ void eval_tables_multi_kernel(EvalMulti m, EvalGeom g, u32 ntab, u64 *tab) {
     const u32 pt = blockIdx.y, id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,33 +119,51 @@ __global__ void eval_tables_multi_kernel(EvalMulti m, EvalGeom g, u32 ntab, u64 
 }
 __global__ __launch_bounds__(256) void eval_cols_multi_kernel(EvalMulti m, EvalGeom g, u32 ntab, const u64 *__restrict__ tabs, u64 *__restrict__ partial) {
     __shared__ u64 red[2 * 256];
-    const u32 t = threadIdx.x, B = blockIdx.x, vcol = blockIdx.y;
-    u32 job = 0;
-    while (job + 1 < m.n_jobs && vcol >= m.col0[job + 1]) job++;
-    const u32 col = vcol - m.col0[job];
-    const u64 *tab = tabs + 2 * (size_t)m.point_of[job] * ntab;
+    const u32 t = threadIdx.x, B = blockIdx.x, lcol = blockIdx.y;
+    u32 lj = 0;
+    while (lj + 1 < m.n_launch_jobs && lcol >= m.lcol0[lj + 1]) lj++;
+    const u32 job = m.launch_job[lj], col = lcol - m.lcol0[lj], job2 = m.pair[job];
+    const bool two = job2 != 0xFFFFFFFFu;                                  // block-uniform
+    const u64 *tab = tabs + 2 * (size_t)m.point_of[job] * ntab, *tab2 = tabs + 2 * (size_t)m.point_of[two ? job2 : job] * ntab;
     const u32 nT = 1u << g.LT, nI = 1u << g.LI;
-    const u64 *zi = tab + 2 * nT, *zb = tab + 2 * (nT + nI);
-    gl2 acc = gl2_make(0, 0);
+    const u64 *zi = tab + 2 * nT, *zb = tab + 2 * (nT + nI), *zi2 = tab2 + 2 * nT, *zb2 = tab2 + 2 * (nT + nI);
+    gl2 acc = gl2_make(0, 0), acc2 = gl2_make(0, 0);
     if (t < nT) {
         const u64 *p = m.coeffs[job] + (size_t)col * m.stride[job] + ((size_t)B << (g.LT + g.LI)) + t;
-        for (u32 i = 0; i < nI; i++) {
-            u64 c = p[(size_t)i << g.LT];
-            acc.a = gl_add(acc.a, gl_mul(c, zi[2 * i]));
-            acc.b = gl_add(acc.b, gl_mul(c, zi[2 * i + 1]));
+        if (two) {
+            for (u32 i = 0; i < nI; i++) {
+                const u64 c = p[(size_t)i << g.LT];
+                acc.a = gl_add(acc.a, gl_mul(c, zi[2 * i]));
+                acc.b = gl_add(acc.b, gl_mul(c, zi[2 * i + 1]));
+                acc2.a = gl_add(acc2.a, gl_mul(c, zi2[2 * i]));
+                acc2.b = gl_add(acc2.b, gl_mul(c, zi2[2 * i + 1]));
+            }
+            acc2 = gl2_mul(acc2, gl2_make(tab2[2 * t], tab2[2 * t + 1]));
+        } else {
+            for (u32 i = 0; i < nI; i++) {
+                const u64 c = p[(size_t)i << g.LT];
+                acc.a = gl_add(acc.a, gl_mul(c, zi[2 * i]));
+                acc.b = gl_add(acc.b, gl_mul(c, zi[2 * i + 1]));
+            }
         }
         acc = gl2_mul(acc, gl2_make(tab[2 * t], tab[2 * t + 1]));
     }
-    red[2 * t] = acc.a; red[2 * t + 1] = acc.b;
-    __syncthreads();
-    for (u32 s = 128; s > 0; s >>= 1) {
-        if (t < s) { red[2 * t] = gl_add(red[2 * t], red[2 * (t + s)]); red[2 * t + 1] = gl_add(red[2 * t + 1], red[2 * (t + s) + 1]); }
+    for (int pass = 0; pass < (two ? 2 : 1); pass++) {
+        const gl2 v = pass ? acc2 : acc;
         __syncthreads();
-    }
-    if (t == 0) {
-        gl2 r = gl2_mul(gl2_make(red[0], red[1]), gl2_make(zb[2 * B], zb[2 * B + 1]));
-        size_t o = ((size_t)vcol << g.LB) + B;
-        partial[2 * o] = r.a; partial[2 * o + 1] = r.b;
+        red[2 * t] = v.a; red[2 * t + 1] = v.b;
+        __syncthreads();
+        for (u32 s = 128; s > 0; s >>= 1) {
+            if (t < s) { red[2 * t] = gl_add(red[2 * t], red[2 * (t + s)]); red[2 * t + 1] = gl_add(red[2 * t + 1], red[2 * (t + s) + 1]); }
+            __syncthreads();
+        }
+        if (t == 0) {
+            const u64 *zz = pass ? zb2 : zb;
+            gl2 r = gl2_mul(gl2_make(red[0], red[1]), gl2_make(zz[2 * B], zz[2 * B + 1]));
+            const u32 vcol = m.col0[pass ? job2 : job] + col;
+            size_t o = ((size_t)vcol << g.LB) + B;
+            partial[2 * o] = r.a; partial[2 * o + 1] = r.b;
+        }
     }
 }
 __global__ void eval_reduce_multi_kernel(EvalMulti m, const u64 *partial, int LB, u64 *unused) {
@@ -171,13 +192,28 @@ int32_t zk_eval_cols_multi(zk_ctx *ctx, int k, u32 n_jobs, const zk_eval_job *jo
     }
     m.col0[n_jobs] = total;
     if (total == 0) return ZK_OK;
+    // pairs: job j and a later job over the same columns at another point (ZK_EVAL_PAIR=0: every job by itself, the A/B switch)
+    static const int pairing = getenv("ZK_EVAL_PAIR") ? atoi(getenv("ZK_EVAL_PAIR")) : 1;
+    bool secondary[ZK_EVAL_MAX_JOBS] = {};
+    u32 ltotal = 0;
+    for (u32 j = 0; j < n_jobs; j++) {
+        m.pair[j] = 0xFFFFFFFFu;
+        if (secondary[j]) continue;
+        if (pairing)
+            for (u32 q = j + 1; q < n_jobs; q++)
+                if (!secondary[q] && jobs[q].coeffs == jobs[j].coeffs && jobs[q].stride == jobs[j].stride && jobs[q].n_cols == jobs[j].n_cols &&
+                    m.point_of[q] != m.point_of[j]) { m.pair[j] = q; secondary[q] = true; break; }
+        m.launch_job[m.n_launch_jobs] = j; m.lcol0[m.n_launch_jobs] = ltotal; m.n_launch_jobs++;
+        ltotal += jobs[j].n_cols;
+    }
+    m.lcol0[m.n_launch_jobs] = ltotal;
     EvalGeom g = eval_geom(k);
     const u32 ntab = (1u << g.LT) + (1u << g.LI) + (1u << g.LB);
     u64 *tab = (u64 *)ctx->alloc((size_t)ntab * m.n_points * 2 * sizeof(u64));
     u64 *partial = (u64 *)ctx->alloc(((size_t)total << g.LB) * 2 * sizeof(u64));
     if (!tab || !partial) { ctx->release(tab); ctx->release(partial); return ctx->fail(ZK_ERR_OOM, "eval_cols_multi: device memory"); }
     ZK_LAUNCH(ctx, "eval_tables", eval_tables_multi_kernel, dim3((ntab + 255) / 256, m.n_points), dim3(256), 0, m, g, ntab, tab);
-    ZK_LAUNCH(ctx, "eval_cols", eval_cols_multi_kernel, dim3(1u << g.LB, total), dim3(256), 0, m, g, ntab, (const u64 *)tab, partial);
+    ZK_LAUNCH(ctx, "eval_cols", eval_cols_multi_kernel, dim3(1u << g.LB, ltotal), dim3(256), 0, m, g, ntab, (const u64 *)tab, partial);
     ZK_LAUNCH(ctx, "eval_reduce", eval_reduce_multi_kernel, dim3((total + 255) / 256), dim3(256), 0, m, (const u64 *)partial, g.LB, (u64 *)nullptr);
     ctx->release(tab); ctx->release(partial);
     return ZK_OK;
