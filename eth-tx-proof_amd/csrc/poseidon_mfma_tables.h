@@ -29,8 +29,8 @@
 // The MDS layers are a special case: their constants are below 2^7, so M * 2^(8b) has ONE non-zero digit, at position b -- output limb a
 // depends on byte a of the twelve state words and on nothing else, the 96 x 96 operand of the general scheme is block-diagonal by byte
 // plane and seven eighths of its products multiply zeros.  An MDS layer therefore runs TWO planes per instruction (round 4: the matrix
-// pipe is NOT hidden behind the vector ALU on this chip -- an i8 32x32x32 instruction holds the SIMD for its 64 cycles, removing all of
-// them makes the leaf hash 28 % faster, DESIGN.md section 5 -- so instruction count on this side matters):
+// instructions are NOT hidden behind the vector ALU in these kernels -- at saturation each cost about 68 cycles of the SIMD, twice its 32
+// cycles of pipe; removing all of them makes the leaf hash 28 % faster, DESIGN.md section 4 -- so instruction count on this side matters):
 //   tile P = 0..3 covers byte planes 2P, 2P+1 = halfword P of every word;  K index (lane half h, byte j < 12) = byte (j & 1) of halfword
 //   P of word 6h + (j >> 1) (j = 12..15: padding);  output row (lane half h', register r < 12) = limb 2P + (r & 1) of word 6h' + (r >> 1).
 // One operand fragment serves all four tiles and all eight layers; 8 instructions per layer and wave instead of 18.
