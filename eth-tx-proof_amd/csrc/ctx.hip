@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "zk_internal.h"
+#include "transcript.h"
 
 void *zk_ctx::alloc(size_t bytes) {
     if (bytes == 0) bytes = 256;
@@ -314,8 +315,15 @@ int32_t zk_ctx_set_host_transcript(zk_ctx *c, int32_t on) {
     if (!c) return ZK_ERR_INVALID_ARG;
     if (c->host_transcript == (on ? 1 : 0)) return ZK_OK;
     // between proofs only: the two challengers keep their sponge states in different places
+    hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     zk_host_transcript_begin_proof(c);
+    // challengers that outlive the switch (zk_challenger_new handles) take their sponge along; a proof's own challenger starts with
+    // TOP_INIT on whichever side is current
+    for (DevChallenger *d : c->live_challengers) {
+        const int32_t rc = on ? zk_host_transcript_adopt(c, d) : zk_host_transcript_hand_back(c, d);
+        if (rc != ZK_OK) return rc;
+    }
     c->host_transcript = on ? 1 : 0;
     return ZK_OK;
 }

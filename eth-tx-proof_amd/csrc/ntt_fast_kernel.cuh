@@ -14,6 +14,7 @@
 #pragma once
 #include "ntt_pass.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #include "ntt_radix.cuh"
 
@@ -28,8 +29,25 @@
 // Two shapes of tile: (A) all rows of the tile in one column (every TILE pass; ROW passes with at least T rows per column) and
 // (B) one row per column (ROW passes of whole transforms, k = W <= 12: the tile holds T columns).  The launcher routes anything else
 // to the LDS radix-2 kernel.
+#ifndef ZK_NTT_PERSIST_DEFAULT
+#define ZK_NTT_PERSIST_DEFAULT 0
+#endif
+#ifndef NTT_SH64            // 0 (tools/ntt_floor.hip only): the round-4 form, every inter-phase twiddle a general product
+#define NTT_SH64 1
+#endif
 template <bool ROW, int W> struct NttGeom {
     static constexpr int P2 = (W - 4) < 4 ? (W - 4) : 4, P3 = W - 4 - P2, TL = 13 - W, R = 1 << (W - 4);
+    // W = 9, 10: the M and L phases together are a 2^(4+P3) <= 64-point transform, whose root w_32 = 2^6 / w_64 = 2^3 is a power of two:
+    // the twiddle between the two phases is a SHIFT, by an amount that depends on the register (compile time) and on the P3 low slot
+    // bits -- which the M mapping of these widths takes from the WAVE number, so that the amount is uniform per wave (round 5)
+    // (W = 9 TILE tiles keep the general products: with sixteen adjacent positions per slot their kernels were at the 128-register limit
+    // already, and the shift form spilled 6-9 registers to scratch there)
+    static constexpr bool SH64 = NTT_SH64 && (P2 == 4) && (P3 == 2 || (P3 == 1 && ROW));
+    // LDS image of the tile.  ROW: row stride RS; SH64 tiles pad one element per 32 slots (+1 per row at W = 10), the others 2^P3 per
+    // 2^(W-4) slots.  TILE: element (t, slot) at slot * T + t; SH64 tiles skip T elements after every 2^(W-4) slots.  With these every
+    // exchange of the SH64 mappings is free of bank conflicts on ds_read_b64 (32-lane groups, 64 banks) except the TILE L reads.
+    static constexpr int RS = !ROW ? 0 : SH64 ? (1 << W) + (1 << (W - 5)) + (W == 10 ? 1 : 0) : (1 << W) + (W >= 8 ? (16 << P3) : 0);
+    static constexpr size_t tile_elems = ROW ? ((size_t)RS << TL) : ((size_t)((1 << W) + (SH64 ? 16 : 0)) << TL);
     // the part of (t, slot) of mapping m (0 = H, 1 = M, 2 = L) that register q contributes; map_X(q) = map_X(0) + these
     static constexpr u32 t_uni(int m, int q) {
         if (!ROW || m == 0) return 0;
@@ -66,7 +84,7 @@ __device__ __forceinline__ u64 ntt_uniform(u64 v) {
 __device__ __forceinline__ u64 ntt_ld(const u64 *sbase, u32 thr_bytes) {
     const u64 b = ntt_uniform((u64)sbase);
 #if NTT_FLOOR
-    return (b + thr_bytes) | 1;
+    return ((b + thr_bytes) * 0x9E3779B97F4A7C15ull) >> 1;     // a well-mixed value below 2^63 (structured values meet the rare-repair paths far too often)
 #else
     return *(const __attribute__((address_space(1))) u64 *)(b + thr_bytes);
 #endif
@@ -83,31 +101,63 @@ template <bool DIT, bool ROW, int W, bool INV, bool CS = false>
 // Two 512-thread workgroups per CU (64-78 KiB of LDS each) need <= 128 VGPRs.
 // CS (coset-merged LDE): the launch covers n_cols << cs_bits VIRTUAL columns; virtual column v = (real column v >> cs_bits, coset slot
 // v & mask): its data sits at column * stride + slot * sub on either side, and its input factors at load_tab + slot * tab_sub.
-__global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
+__global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
     static_assert(W >= 4 && W <= 12 && (ROW || W <= 10), "digit width");
     constexpr int P2 = (W - 4) < 4 ? (W - 4) : 4;
     constexpr int P3 = W - 4 - P2;
     constexpr int R = 1 << (W - 4);
     constexpr int G2 = 16 >> P2, G3 = 16 >> P3;
     constexpr bool SWZ = ROW && W >= 8;
-    constexpr int RS = (1 << W) + (SWZ ? (16 << P3) : 0);         // LDS row stride of a ROW tile, in elements
+    constexpr bool SH64 = NttGeom<ROW, W>::SH64;
+    constexpr int RS = ROW ? NttGeom<ROW, W>::RS : (1 << W);      // LDS row stride of a ROW tile, in elements
     extern __shared__ u64 sh[];
+    __shared__ u32 redo_vote;
     // the tile always holds 2^13 elements (T = 2^(13-W) rows or adjacent positions): with the tile shape a compile-time constant
     // every LDS index of an exchange is the thread's base plus an immediate offset (the launcher routes other shapes elsewhere)
     constexpr int TL = 13 - W;
-    const int S = p.S;
-    const u32 T = 1u << TL, tid = threadIdx.x;
+    const u32 T = 1u << TL, tid0 = threadIdx.x;
     constexpr u32 nact = 512;
     constexpr bool act = true, wact = true;
-    const size_t n = (size_t)1 << p.k;
-    const u64 *__restrict__ RW = p.tw_full;
+    const u64 *__restrict__ RW = p_arg.tw_full;
 
+    // the 2^W digit roots go to LDS behind the tile: the inter-phase twiddles are per-lane gathers, and an LDS gather costs a
+    // fraction of an L1-hit global load's latency
+    u64 *shRW = sh + NttGeom<ROW, W>::tile_elems;
+    for (u32 i = tid0; i < (1u << W); i += 512) shRW[i] = RW[i];
+    // Persistent launch (round 5, p.n_blocks > 0): the grid is a fixed number of workgroups and workgroup b takes the tiles b, b + grid,
+    // b + 2 grid, ... -- no wait for a tile's stores to drain and for the next workgroup to be set up between two tiles of a CU slot, the
+    // roots are staged once.  grid % 8 == 0 keeps a workgroup's tiles on "its" XCD numbering (the pairing of col_fast == 2 holds).
+    const u32 nblk = p_arg.n_blocks ? p_arg.n_blocks : gridDim.x;
+    const u32 wave_id0 = (u32)__builtin_amdgcn_readfirstlane((int)(tid0 >> 6));
+    for (u32 bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
+    // every wave is done with the LDS image of the previous tile.  An LDS-only barrier: __syncthreads() also waits for the previous
+    // tile's global STORES to drain (its fence covers global memory), and this tile's loads would queue up behind that wait
+    if (bid != blockIdx.x) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+    // the thread id is made opaque once per tile: everything below that depends on the thread alone (exchange indices, byte offsets of
+    // the three mappings, row limits) would otherwise be hoisted out of the tile loop and kept alive across it -- 30 more registers
+    // than the 128 that two workgroups per CU allow, i.e. scratch
+    // (rebuilt from the wave number -- a scalar -- and the lane number, so that not even the id itself occupies a vector register
+    // across the loop)
+    u32 tid = (wave_id0 << 6) + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(tid));
+    if (tid == 0) redo_vote = 0;                                      // set (after the barrier inside compute) by any wave that skipped a rare repair
+    // ... and the pass parameters are read from the kernel-argument segment again in every tile (scalar loads that hit the scalar cache)
+    // instead of staying in ~50 scalar registers across the loop, which spilled scalars into vector lanes
+    const __attribute__((address_space(4))) PassParams *kp = (const __attribute__((address_space(4))) PassParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const __attribute__((address_space(4))) PassParams &p = *kp;
+    const int S = p.S;
+    const size_t n = (size_t)1 << p.k;
     size_t col = 0, base = 0, row0 = 0, rows_per_col = 1, total_rows = 0;
     if (ROW) {
         rows_per_col = n >> W; total_rows = rows_per_col * ((size_t)p.n_cols << (CS ? p.cs_bits : 0));
         const u32 vcols = (u32)p.n_cols << (CS ? p.cs_bits : 0);
-        if (p.col_fast) row0 = (size_t)(blockIdx.x % vcols) * rows_per_col + ((size_t)(blockIdx.x / vcols) << TL);
-        else row0 = (size_t)blockIdx.x << TL;
+        if (p.col_fast) row0 = (size_t)(bid % vcols) * rows_per_col + ((size_t)(bid / vcols) << TL);
+        else row0 = (size_t)bid << TL;
     } else {
         size_t tiles_per_block = ((size_t)1 << S) >> TL, tiles_per_col = (n >> (W + S)) * tiles_per_block;
         size_t rem;
@@ -130,26 +180,26 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
             // TILE passes fetched every line twice (FETCH_SIZE 2.14x the data against 1.09x for ROW passes and for TILE passes at
             // W = 9, profiles/r03e_pmc_tile_fetch_ab_and_whole_proof.json).  Workgroups go to the XCDs round robin (blockIdx % 8), so
             // blockIdx b and b + 8 are consecutive on one XCD: give those two the two halves of the same lines.
-            const u32 b = blockIdx.x, xcd = b & 7u, m = b >> 3;
+            const u32 b = bid, xcd = b & 7u, m = b >> 3;
             const u32 l = (m & 1u) + 2u * (xcd + 8u * (m >> 1));
             u32 c, u; split(l >> 1, (u32)(tiles_per_col >> 1), c, u);
             col = c; rem = 2 * (size_t)u + (l & 1u);
-        } else if (p.col_fast) { u32 c, u; split(blockIdx.x, (u32)tiles_per_col, c, u); col = c; rem = u; }
-        else { col = blockIdx.x / tiles_per_col; rem = blockIdx.x % tiles_per_col; }
+        } else if (p.col_fast) { u32 c, u; split(bid, (u32)tiles_per_col, c, u); col = c; rem = u; }
+        else { col = bid / tiles_per_col; rem = bid % tiles_per_col; }
         base = ((rem / tiles_per_block) << (W + S)) + ((rem % tiles_per_block) << TL);
     }
-    // the 2^W digit roots go to LDS behind the tile: the inter-phase twiddles are per-lane gathers, and an LDS gather costs a
-    // fraction of an L1-hit global load's latency
-    u64 *shRW = sh + (ROW ? ((size_t)RS << TL) : ((size_t)1 << (W + TL)));
-    for (u32 i = tid; i < (1u << W); i += 512) shRW[i] = RW[i];
-
     // ROW tiles: 2^P3 padding elements after every block of R = 2^(W-4) slots (instead of an XOR swizzle): the M-phase lanes, which
     // walk slots R apart, then spread over the LDS banks, and -- unlike an XOR -- the padded index of register q is the thread's
     // base plus a compile-time constant in all three mappings, so an exchange costs no address arithmetic per element.
     auto lds_idx = [&](u32 t, u32 slot) -> u32 {
+        if (SH64) return ROW ? t * (u32)RS + slot + (slot >> 5) : ((slot + (slot >> (W - 4))) << TL) + t;
         if (ROW) return SWZ ? t * (u32)RS + slot + ((slot >> (W - 4)) << P3) : (t << W) + slot;
         return (slot << TL) + t;
     };
+    // SH64: the low slot bits of the M mapping, uniform per wave (a scalar: the shift twiddles branch on it)
+    u32 wave_id = wave_id0;
+    asm volatile("" : "+s"(wave_id));                                 // opaque per tile, like tid: nothing derived from it is kept across the loop
+    const u32 lo_uni = wave_id & ((1u << P3) - 1);
     // ---- thread <-> (t, slot) for register q in each mapping
     auto map_H = [&](int q, u32 &t, u32 &slot) {
         u32 r;
@@ -159,6 +209,21 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
     auto map_M = [&](int q, u32 &t, u32 &slot) {
         const int g = q >> P2, i = q & ((1 << P2) - 1);
         u32 c = tid + nact * g, hi, lo;
+        if (SH64) {
+            // lo from the wave number; the lanes run over hi and the low bits of t in the order that keeps each 32-lane group on 32
+            // different banks of the padded image (tools/ntt_lds_banks.py): g == 0 here (P2 == 4)
+            const u32 l = tid & 63u, w = wave_id;
+            lo = lo_uni;
+            if (ROW) {
+                if (W == 10) { hi = (l >> 1) & 15u; t = ((w >> 2) << 2) | ((l >> 5) << 1) | (l & 1u); }
+                else { hi = l & 15u; t = ((w >> 1) << 2) | (l >> 4); }
+            } else {
+                if (W == 10) { t = l & 7u; hi = (l >> 3) | ((w >> 2) << 3); }
+                else { t = l & 15u; hi = (l >> 4) | ((w >> 1) << 2); }
+            }
+            slot = (hi << (P2 + P3)) | ((u32)i << P3) | lo;
+            return;
+        }
         if (ROW) { lo = c & ((1u << P3) - 1); hi = (c >> P3) & 15; t = c >> (P3 + 4); }
         else { t = c & (T - 1); u32 rest = c >> TL; lo = rest & ((1u << P3) - 1); hi = rest >> P3; }
         slot = (hi << (P2 + P3)) | ((u32)i << P3) | lo;
@@ -278,7 +343,9 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
             if (wact) {
 #pragma unroll
                 for (int g = 0; g < G2; g++) radix_net<P2, false, INV>(fx, x, g << P2, tw16);
-                if (P3 > 0) {
+                if constexpr (SH64 && !std::remove_reference_t<decltype(fx)>::exact) {
+                    ntt_tw64<P3, INV>(fx, x, lo_uni);                       // w_{2^(4+P3)}^(rev(i) lo): shifts, lo uniform per wave
+                } else if (P3 > 0) {
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
                         const int i = q & ((1 << P2) - 1);
@@ -304,27 +371,48 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
             if (wact) {
 #pragma unroll
                 for (int g = 0; g < G3; g++) radix_net<P3, true, INV>(fx, x, g << P3, tw16);
+                // the factor that follows the L phase, w_{2^W}^(k_low rev(upper slot bits)), splits into w_{2^(4+P3)}^(k_low rev4(s_mid)) and
+                // w_{2^W}^(k_low rev4(s_top)).  SH64: the first part (order 32 / 64: shifts) is applied in the M mapping, where s_mid is the
+                // register and k_low the wave's `lo`, and the second joins the factor that follows the M phase
+                if constexpr (!SH64) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int i = q & ((1 << P3) - 1);
-                    if (i == 0) continue;
-                    u32 t, slot; map_L(q, t, slot);
-                    x[q] = fx.mulw(x[q], shRW[act ? (u32)i * bitrev_u32(slot >> P3, W - P3) : 0]);
+                    for (int q = 0; q < 16; q++) {
+                        const int i = q & ((1 << P3) - 1);
+                        if (i == 0) continue;
+                        u32 t, slot; map_L(q, t, slot);
+                        x[q] = fx.mulw(x[q], shRW[act ? (u32)i * bitrev_u32(slot >> P3, W - P3) : 0]);
+                    }
                 }
             }
             to_lds(2); __syncthreads(); from_lds(1);
         }
         if (P2 > 0) {
             if (wact) {
+                if constexpr (SH64) {
+                    if constexpr (!std::remove_reference_t<decltype(fx)>::exact) ntt_tw64<P3, INV>(fx, x, lo_uni);
+                    else {
+#pragma unroll
+                        for (int q = 1; q < 16; q++) x[q] = fx.mulw(x[q], shRW[(BR<4>::rev(q) * lo_uni) << 4]);
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < G2; g++) radix_net<P2, true, INV>(fx, x, g << P2, tw16);
+                if constexpr (SH64) {
+                    // w_{2^W}^(rev4(s_top) (k_low + 2^P3 k_mid)): k_mid the register, k_low = lo, s_top = hi
+                    u32 t, slot; map_M(0, t, slot);
+                    const u32 rh = bitrev_u32(slot >> (P2 + P3), 4);
+                    if (lo_uni != 0) x[0] = fx.mulw(x[0], shRW[rh * lo_uni]);
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int i = q & ((1 << P2) - 1);
-                    if (i == 0) continue;
-                    u32 t, slot; map_M(q, t, slot);
-                    u32 hi = slot >> (P2 + P3);
-                    x[q] = fx.mulw(x[q], shRW[act ? ((u32)i * bitrev_u32(hi, 4)) << P3 : 0]);
+                    for (int q = 1; q < 16; q++) x[q] = fx.mulw(x[q], shRW[rh * (lo_uni + ((u32)q << P3))]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int i = q & ((1 << P2) - 1);
+                        if (i == 0) continue;
+                        u32 t, slot; map_M(q, t, slot);
+                        u32 hi = slot >> (P2 + P3);
+                        x[q] = fx.mulw(x[q], shRW[act ? ((u32)i * bitrev_u32(hi, 4)) << P3 : 0]);
+                    }
                 }
             }
             to_lds(1); __syncthreads(); from_lds(0);
@@ -343,11 +431,18 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
         compute(gf);
         // a skipped rare repair anywhere in the workgroup (waves exchange through LDS): redo the tile with every repair in place
 #ifndef ZK_ISA_COUNT_FAST_ONLY      // analysis builds (tools/isa_mix.py) drop the exact twin so that the static mix is the fast path's
-        if (__syncthreads_or((gf.fl != 0) | p.force_redo)) { glx<true> ge; ge.fl = 0; compute(ge); }
+        // (own one-barrier vote instead of __syncthreads_or: the library's goes through three barriers and keeps the three thread
+        // indices alive across the tile loop; the word was cleared behind this tile's first barrier, see the top of the loop)
+        if ((gf.fl != 0) | p.force_redo) redo_vote = 1u;
+        __syncthreads();
+        if (redo_vote != 0) { glx<true> ge; ge.fl = 0; compute(ge); }
 #endif
     }
 
     // ---------------------------------------------------------------- store
+    // (the thread id once more from scratch: one register less alive across the networks)
+    tid = (wave_id0 << 6) + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(tid));
     constexpr int LAST_DIF = FIRST_DIT;
     constexpr int SMAP = (DIT || ROW) ? 0 : LAST_DIF;                  // mapping of the plain store (DIF ROW tiles exchange into mapping 0 first)
     if (DIT && p.permute_out) {
@@ -392,7 +487,7 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
                 ntt_st(p.out + ub, sc_thr, v);
             }
         }
-        return;
+        continue;
     }
     if (!DIT && ROW && LAST_DIF != 0) { __syncthreads(); to_lds(LAST_DIF); __syncthreads(); from_lds(0); }
     // same structure as the load side: guarded batched factor loads, products in wave-uniform control flow, guarded stores;
@@ -430,6 +525,7 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p) {
         if ((gf.fl != 0) | p.force_redo) { glx<true> ge; ge.fl = 0; store_plain(ge); }
 #endif
     }
+    }       // tiles of this workgroup
 }
 
 
@@ -441,9 +537,14 @@ static void ntt_fast_launch_wi(zk_ctx *ctx, const PassParams &p, const char *nam
     const size_t vcols = (size_t)p.n_cols << (CS ? p.cs_bits : 0);
     if (ROW) { size_t rows = (n >> p.W) * vcols; blocks = (rows + ((size_t)1 << p.TL) - 1) >> p.TL; }
     else blocks = ((n >> p.W) >> p.TL) * vcols;
-    constexpr int P2 = (W - 4) < 4 ? (W - 4) : 4, P3 = W - 4 - P2;
-    const size_t row_stride = ((size_t)1 << W) + ((ROW && W >= 8) ? ((size_t)16 << P3) : 0);      // == RS in the kernel
-    size_t shmem = ((ROW ? (row_stride << p.TL) : ((size_t)1 << (p.W + p.TL))) + ((size_t)1 << p.W)) * sizeof(u64);
+    size_t shmem = (NttGeom<ROW, W>::tile_elems + ((size_t)1 << W)) * sizeof(u64);              // the tile image + the 2^W digit roots
+    // persistent form: ZK_NTT_PERSIST workgroups (a multiple of 8; two fit a CU) walk the tiles
+    static const int persist = getenv("ZK_NTT_PERSIST") ? atoi(getenv("ZK_NTT_PERSIST")) & ~7 : ZK_NTT_PERSIST_DEFAULT;
+    if (persist > 0 && blocks > (size_t)persist) {
+        PassParams q = p; q.n_blocks = (unsigned)blocks;
+        ZK_LAUNCH(ctx, name, (ntt_fast_kernel<DIT, ROW, W, INV, CS>), dim3((unsigned)persist), dim3(512), shmem, q);
+        return;
+    }
     ZK_LAUNCH(ctx, name, (ntt_fast_kernel<DIT, ROW, W, INV, CS>), dim3((unsigned)blocks), dim3(512), shmem, p);
 }
 template <bool DIT, bool ROW, bool INV, bool CS>

@@ -27,6 +27,7 @@ struct PassParams {
     // virtual column v = (column v >> cs_bits, slot v & mask) sits at column * stride + slot * sub; its factors at load_tab + slot * tab_sub
     int cs_bits;
     size_t in_sub, out_sub, tab_sub;
+    unsigned n_blocks;              // register-radix kernel, persistent launch: number of tiles (0: one workgroup per tile, the grid says it)
 };
 
 __device__ __forceinline__ u64 tab2(const u64 *A, const u64 *B, u32 x) { return gl_mul(A[x & 2047], B[x >> 11]); }

@@ -174,7 +174,7 @@ template <bool EXACT, int NC = 2> struct perm {
                 b[1] = (int)__builtin_amdgcn_perm(x[c][P >> 1][3], x[c][P >> 1][2], sel);
                 b[2] = (int)__builtin_amdgcn_perm(x[c][P >> 1][5], x[c][P >> 1][4], sel);
                 b[3] = 0;
-                const psdm_v16i acc = PSDM_MFMA(a, b, cin);
+                psdm_v16i acc = PSDM_MFMA(a, b, cin);
 #pragma unroll
                 for (int i = 0; i < 6; i++) t[c][P][i] = ((u32)acc[2 * i + 1] << 8) + (u32)acc[2 * i];
                 // Registers 12..15 of the result are padding rows and nothing reads them -- which makes them free registers for the compiler
@@ -182,8 +182,14 @@ template <bool EXACT, int NC = 2> struct perm {
                 // later.  hipcc pads its own instructions against that (write after write on an in-flight result), but the vector
                 // instructions inside the inline-asm blocks of the s-boxes are invisible to its hazard recognizer: a value they had just
                 // put into one of the four was overwritten (the second permutation of every pair came out wrong whenever register
-                // pressure made the allocator take those registers).  The whole result stays live until its limbs have been read.
-                asm volatile("" : : "v"(acc));
+                // pressure made the allocator take those registers).  The whole result stays live until its limbs have been read: the
+                // empty statement READS AND WRITES all sixteen registers, so it cannot move above the limb reads before it (they would
+                // see its "new" value) and nothing else can be given registers 12..15 before it; the first limb read is a compiler-made
+                // instruction, which hipcc holds back until the matrix instruction has written its result (an input-only
+                // operand ordered nothing).  tools/asm_clobber_audit.py --code checks the built code objects for the pattern.
+#ifndef PSDM_NO_RESULT_LIVENESS       // (defined by the negative control of tests/test_abi_cpu.py only: the round-4 defect, for the code-object audit to find)
+                asm volatile("" : "+v"(acc));
+#endif
             }
         }
 #pragma unroll

@@ -260,6 +260,46 @@ void zk_host_transcript_begin_proof(zk_ctx *ctx) {
     H->idle_cv.wait(lk, [H] { return H->q.empty() && !H->busy; });
     H->ring_used = 0;
 }
+// ---- the switch with challengers alive: the device path keeps a sponge in its DevChallenger block, the host path in
+// H->sponges.  Both callers hold the context between proofs (stream synchronised, queue drained).  Upstream's output buffer is the first
+// eight state words as of the last permutation, so (state, inbuf, n_in, n_out) is the whole challenger on either side.
+int32_t zk_host_transcript_adopt(zk_ctx *ctx, DevChallenger *d) {
+    zk_host_transcript *H = mailbox(ctx);
+    if (!H) return ctx->fail(ZK_ERR_OOM, "host transcript: pinned memory");
+    DevChallenger h;
+    if (hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "host transcript: challenger download");
+    psdh::Sponge S;
+    for (int i = 0; i < 12; i++) S.state[i] = h.state[i];
+    for (int i = 0; i < 8; i++) S.inbuf[i] = h.inbuf[i];
+    S.n_in = h.n_in; S.n_out = h.n_out;
+    std::lock_guard<std::mutex> lk(H->mu);
+    H->sponges[d] = S;
+    return ZK_OK;
+}
+int32_t zk_host_transcript_hand_back(zk_ctx *ctx, DevChallenger *d) {
+    zk_host_transcript *H = ctx->hmb;
+    if (!H) return ZK_OK;                                  // the host path never ran: the device block is current
+    DevChallenger h;
+    {
+        std::lock_guard<std::mutex> lk(H->mu);
+        auto it = H->sponges.find(d);
+        if (it == H->sponges.end()) return ZK_OK;
+        const psdh::Sponge &S = it->second;
+        for (int i = 0; i < 12; i++) h.state[i] = S.state[i];
+        for (int i = 0; i < 8; i++) { h.inbuf[i] = S.inbuf[i]; h.outbuf[i] = S.state[i]; }
+        h.n_in = S.n_in; h.n_out = S.n_out;
+        H->sponges.erase(it);
+    }
+    if (hipMemcpy(d, &h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) return ctx->fail(ZK_ERR_HIP, "host transcript: challenger upload");
+    return ZK_OK;
+}
+void zk_host_transcript_forget(zk_ctx *ctx, const DevChallenger *d) {
+    zk_host_transcript *H = ctx->hmb;
+    if (!H) return;
+    std::unique_lock<std::mutex> lk(H->mu);
+    H->idle_cv.wait(lk, [H] { return H->q.empty() && !H->busy; });       // a trailing job may still name it
+    H->sponges.erase(d);
+}
 int32_t zk_host_transcript_take_error(zk_ctx *ctx) { return ctx->hmb ? ctx->hmb->error.exchange(0) : 0; }
 
 int32_t zk_host_transcript_run(zk_ctx *ctx, DevChallenger *c, const TOpList &ops) {

@@ -190,11 +190,16 @@ int32_t zk_challenger_new(zk_ctx *ctx, zk_challenger **out) {
     if (!h->d || !h->scratch) { delete h; return ZK_ERR_OOM; }
     TOpList a = {}; a.n = 1; a.op[0].kind = TOP_INIT;
     zk_transcript_run(ctx, h->d, a);
+    ctx->live_challengers.push_back(h->d);
     *out = h;
     return ZK_OK;
 }
 int32_t zk_challenger_free(zk_challenger *h) {
     if (!h) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(h->ctx->device);
+    zk_ctx_synchronize(h->ctx);
+    zk_host_transcript_forget(h->ctx, h->d);               // its host-side sponge, if the host path holds one
+    { auto &v = h->ctx->live_challengers; for (size_t i = 0; i < v.size(); i++) if (v[i] == h->d) { v.erase(v.begin() + i); break; } }
     h->ctx->release(h->d); h->ctx->release(h->scratch);
     delete h;
     return ZK_OK;

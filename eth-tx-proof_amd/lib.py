@@ -336,10 +336,14 @@ class Challenger:
         self.ctx._chk(lib().zk_challenger_compact(self.h, _p(out)), "zk_challenger_compact")
         return out
 
+    def free(self):
+        if self.h and self.ctx.h:
+            lib().zk_challenger_free(self.h)
+        self.h = C.c_void_p()
+
     def __del__(self):
         try:
-            if self.h and self.ctx.h:
-                lib().zk_challenger_free(self.h)
+            self.free()
         except Exception:
             pass
 

@@ -106,7 +106,12 @@ class ProverState:
         # host_transcript: in the latency regime (the rule of chain_overlap) the sponge runs on a host thread; False keeps it on the device always
         # ("always" -- also what ZK_TRANSCRIPT_HOST=1 in the environment means here -- keeps it on the host in every regime)
         import os as _os
-        self.host_transcript = "always" if (host_transcript == "always" or _os.environ.get("ZK_TRANSCRIPT_HOST", "0") not in ("", "0")) else bool(host_transcript)
+        # ZK_TRANSCRIPT_HOST in the environment decides when set: "0" = never on the host, anything else = always
+        env_ht = _os.environ.get("ZK_TRANSCRIPT_HOST", "")
+        if env_ht != "":
+            self.host_transcript = False if env_ht == "0" else "always"
+        else:
+            self.host_transcript = "always" if host_transcript == "always" else bool(host_transcript)
         self.chain_overlap = chain_overlap if chain_overlap in (True, False) else "auto"
         self.overlap_max_inflight = 2
         self._active, self._active_lock = 0, threading.Lock()

@@ -265,6 +265,38 @@ def test_inline_asm_declares_every_implicit_register_it_writes():
     assert not sites, "SCC overwritten between a scalar add and its add-with-carry:\n" + "\n".join(sites[:20])
 
 
+def test_no_vector_instruction_touches_a_matrix_result_inside_its_hazard_window(tmp_path):
+    """Rules 2-3 of DESIGN.md section 9, checked on the BUILT code: a matrix instruction writes its result
+    registers when it finishes, hipcc pads its own instructions against touching them earlier but cannot see into inline-asm blocks, and
+    round 4's wrong second permutation was an s-box block's write into a padding register of a result in flight.  The scan
+    (tools/asm_clobber_audit.py: mfma_result_hazards) must find nothing in the shipped library, must find nothing in the test kernels of
+    tools/psdm_test.hip as they are -- and must find the defect when the statement that keeps the whole result alive is compiled out
+    (-DPSDM_NO_RESULT_LIVENESS: the pre-fix shape, in exactly the kernels bounded to three waves per SIMD)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import asm_clobber_audit as A
+    from eth_tx_proof_amd import lib as zl
+    zl.build()
+    seen, sites = A.mfma_result_hazards_in_code_objects(zl._SO)
+    assert seen > 500, "only %d matrix instructions found: is the disassembler there?" % seen
+    assert not sites, "\n".join(sites[:20])
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(root, "eth-tx-proof_amd", "csrc")
+    found = {}
+    for tag, extra in (("as_shipped", []), ("pre_fix", ["-DPSDM_NO_RESULT_LIVENESS"])):
+        obj = tmp_path / ("psdm_%s.o" % tag)
+        out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + csrc] + extra + ["-c", os.path.join(root, "tools", "psdm_test.hip"), "-o", str(obj)],
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        found[tag] = A.mfma_result_hazards_in_code_objects(str(obj))
+    assert found["as_shipped"][0] > 100 and not found["as_shipped"][1], found["as_shipped"][1][:5]
+    assert any("k_level" in s for s in found["pre_fix"][1]), "the pre-fix shape was not flagged: %r" % (found["pre_fix"],)
+
+
 def test_host_challenger_permutation_and_sponge_against_upstream_vectors_and_the_oracle(zk):
     """The host-side challenger (zk_ctx_set_host_transcript) runs its own scalar Poseidon and duplex sponge on CPU threads; both are plain
     host code and are pinned HERE, without a GPU: the permutation to upstream's four `test_vectors` KATs (tests/golden/vectors.json) and,

@@ -498,6 +498,57 @@ def test_host_side_challenger_gives_the_same_proofs(zk, orc):
 
 
 @pytest.mark.gpu
+def test_a_challenger_that_outlives_the_switch_keeps_its_sponge(zk, orc):
+    """zk_ctx_set_host_transcript moves the sponge of every live zk_challenger between its two homes (DevChallenger block <->
+    host map), in every buffer state: pending inputs, unread outputs, right after a permutation.  One oracle challenger is the reference
+    for a handle that crosses the switch six times, with proofs of the same context in between; a second handle is created on the host side
+    and freed there (its map entry must go with it)."""
+    from eth_tx_proof_amd import air
+    cfg = _cfg()
+    c2 = zk.Context(0)
+    try:
+        prog = air.cpu_like_air(9, 2)
+        tr, pub = orc.synth_trace(9, 8, 5)
+        items = [(prog, 8, tr, pub)]
+        rc, ref = orc.prove(cfg, items)
+        assert rc == 0
+        xs = np.array([(i * 0xD1B54A32D192ED03) % 0xFFFFFFFF00000001 for i in range(1, 400)], dtype=np.uint64)
+        ch, och = c2.challenger(), orc.Challenger()
+        at = 0
+        def step(n_obs, n_get):
+            nonlocal at
+            if n_obs:
+                ch.observe(xs[at:at + n_obs]); och.observe(xs[at:at + n_obs]); at += n_obs
+            if n_get:
+                assert (ch.get(n_get) == och.get(n_get)).all()
+        step(5, 0)                                   # pending inputs cross to the host
+        c2.set_host_transcript(True)
+        step(3, 2)                                   # completes the chunk there; 6 outputs left unread
+        c2.set_host_transcript(False)
+        step(0, 3)                                   # ... and are read on the device
+        assert (zk.prove_tables(c2, cfg, items) == ref).all()
+        step(11, 0)
+        c2.set_host_transcript(True)
+        assert (zk.prove_tables(c2, cfg, items) == ref).all()
+        other = c2.challenger(); other.observe(xs[:9]); oo = orc.Challenger(); oo.observe(xs[:9])
+        assert (other.get(2) == oo.get(2)).all()
+        other.free()
+        step(0, 9)                                   # more than one buffer of challenges
+        c2.set_host_transcript(False)
+        step(8, 1)
+        c2.set_host_transcript(True)
+        c2.set_host_transcript(False)
+        step(1, 1)
+        assert (ch.compact() == och.compact()).all()
+        c2.set_host_transcript(True)
+        step(2, 2)
+        assert (ch.compact() == och.compact()).all()
+        c2.set_host_transcript(False)
+    finally:
+        c2.close()
+
+
+@pytest.mark.gpu
 def test_every_block_across_a_4gib_boundary_gives_the_same_proofs(zk, orc, monkeypatch):
     """The layout behind the GPU memory faults of rounds 1-4: a device block that straddles a 4 GiB boundary, read or
     written behind the boundary by a kernel whose pointer arithmetic had lost its carry (an asm block overwrote SCC between s_add_u32 and

@@ -126,22 +126,34 @@ def audit(dirs=None):
     return n, bad
 
 
-def scc_pairs_in_code_objects(lib=None, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
-    """The same defect seen from the built code: an instruction that writes SCC -- other than the compiler's own save/restore idiom
-    (s_cselect_b64 mask, -1, 0 ... s_cmp_lg_u64 mask, 0) -- between an s_add_u32 / s_sub_u32 and the s_addc_u32 / s_subb_u32 that consumes its carry.
-    Returns (number of add/addc pairs seen, list of offending sites)."""
+_DISASM = {}
+
+
+def disassemble_code_objects(lib=None, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    """llvm-objdump -d of every gfx950 code object of a library / object file / bare .co, memoised per (path, mtime): the scans below share it"""
     import subprocess
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources as kr
     lib = lib or os.path.join(ROOT, "eth-tx-proof_amd", "csrc", "libzkgl_hip.so")
-    images = [lib] if lib.endswith(".co") else None
-    blobs = [open(lib, "rb").read()] if images else [[x for x in co if isinstance(x, (bytes, bytearray))][0] for co in kr.code_objects(lib)]
+    key = (os.path.abspath(lib), os.path.getmtime(lib))
+    if key not in _DISASM:
+        blobs = [open(lib, "rb").read()] if lib.endswith(".co") else [[x for x in co if isinstance(x, (bytes, bytearray))][0] for co in kr.code_objects(lib)]
+        texts = []
+        for blob in blobs:
+            with tempfile.NamedTemporaryFile(suffix=".co") as tf:
+                tf.write(blob); tf.flush()
+                texts.append(subprocess.run([objdump, "-d", "--mcpu=gfx950", tf.name], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode(errors="replace"))
+        _DISASM[key] = texts
+    return _DISASM[key]
+
+
+def scc_pairs_in_code_objects(lib=None, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    """The same defect seen from the built code: an instruction that writes SCC -- other than the compiler's own save/restore idiom
+    (s_cselect_b64 mask, -1, 0 ... s_cmp_lg_u64 mask, 0) -- between an s_add_u32 / s_sub_u32 and the s_addc_u32 / s_subb_u32 that consumes its carry.
+    Returns (number of add/addc pairs seen, list of offending sites)."""
     pairs, sites = 0, []
-    for blob in blobs:
-        with tempfile.NamedTemporaryFile(suffix=".co") as tf:
-            tf.write(blob); tf.flush()
-            asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", tf.name], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode(errors="replace")
+    for asm in disassemble_code_objects(lib, objdump):
         fn, pend, dirty, saved = None, None, None, None
         for ln in asm.splitlines():
             m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
@@ -175,6 +187,77 @@ def scc_pairs_in_code_objects(lib=None, objdump="/opt/rocm/lib/llvm/bin/llvm-obj
     return pairs, sites
 
 
+# ---- rules 2-3 of DESIGN.md section 9 from the built code.  On gfx950 the result registers of a matrix instruction are
+# written when it finishes, and nothing in the hardware holds back a vector instruction that reads OR WRITES one of them earlier: hipcc
+# pads its own instructions (GCNHazardRecognizer: for an N-pass XDL instruction N + 3 wait states before a VALU read or write of vDst),
+# but instructions inside inline-asm blocks are invisible to it.  An inline-asm write into a padding register of an in-flight result was
+# round 4's "second permutation of every pair is wrong".  The scan below needs no knowledge of where asm blocks are: for every v_mfma it
+# walks the following instructions, counts wait states (one per instruction, s_nop N = N + 1) and reports any instruction other than a
+# matrix instruction that names a register of the result before the budget is used up.
+# passes of the instructions this code base uses on gfx950 (4 cycles each: v_mfma_i32_32x32x32_i8 holds the matrix pipe 32 cycles,
+# tools/mfma_overlap.hip); hipcc's own first readers sit 12 wait states behind it, budget 8 + 3 = 11
+MFMA_PASSES = {"32x32": 8, "16x16": 4, "4x4": 2}
+
+
+def _regs(tok):
+    """the VGPRs / AGPRs an operand token names: 'v5' -> {('v',5)}, 'a[0:15]' -> {('a',0)..('a',15)}"""
+    out = set()
+    for kind, lo, hi in re.findall(r"\b([va])\[(\d+):(\d+)\]", tok):
+        out.update((kind, i) for i in range(int(lo), int(hi) + 1))
+    for kind, n in re.findall(r"(?<![\w\[:])([va])(\d+)\b", tok):
+        out.add((kind, int(n)))
+    return out
+
+
+def mfma_result_hazards(asm_text):
+    """(matrix instructions seen, offending sites) of one disassembly (llvm-objdump -d)"""
+    seen, sites = 0, []
+    fn, lines = None, []
+    for ln in asm_text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+        if m:
+            fn = m.group(1)
+            continue
+        t = ln.strip().split("//")[0].strip()
+        if t and not t.endswith(":"):
+            lines.append((fn, t))
+    for i, (fn, t) in enumerate(lines):
+        op = t.split()[0]
+        if not op.startswith("v_mfma") and not op.startswith("v_smfmac"):
+            continue
+        seen += 1
+        shape = re.search(r"_(\d+x\d+)x\d+", op)
+        passes = MFMA_PASSES.get(shape.group(1) if shape else "", 8)
+        budget = passes + 3
+        dst = _regs(t[len(op):].split(",")[0])
+        ws, j = 0, i + 1
+        while j < len(lines) and ws < budget and lines[j][0] == fn:
+            u = lines[j][1]
+            uop = u.split()[0]
+            if uop == "s_nop":
+                ws += int(u.split()[1], 0) + 1
+            else:
+                if uop in ("s_endpgm", "s_branch", "s_setpc_b64", "s_swappc_b64") or uop.startswith("s_cbranch"):
+                    break                                               # straight-line code only (the kernels of interest are)
+                if uop.startswith("v_mfma") or uop.startswith("v_smfmac"):
+                    if _regs(u[len(uop):].split(",")[0]) & dst:
+                        break                                           # the next link of an accumulation chain: it is checked as its own start
+                elif _regs(u[len(uop):]) & dst:
+                    sites.append("%s: %s  ...  %d wait state(s) later (< %d): %s" % (fn, t, ws, budget, u))
+                    break
+                ws += 1
+            j += 1
+    return seen, sites
+
+
+def mfma_result_hazards_in_code_objects(lib=None, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    seen, sites = 0, []
+    for asm in disassemble_code_objects(lib, objdump):
+        n, s = mfma_result_hazards(asm)
+        seen += n; sites += s
+    return seen, sites
+
+
 if __name__ == "__main__":
     n, bad = audit()
     print("%d asm statements, %d problems" % (n, len(bad)))
@@ -183,6 +266,12 @@ if __name__ == "__main__":
     if "--code" in sys.argv:
         pairs, sites = scc_pairs_in_code_objects(sys.argv[sys.argv.index("--code") + 1] if len(sys.argv) > sys.argv.index("--code") + 1 else None)
         print("%d scalar add / add-with-carry pairs in the code objects, %d with SCC overwritten in between" % (pairs, len(sites)))
+        for s in sites[:20]:
+            print("  " + s)
+        bad += sites
+        lib = sys.argv[sys.argv.index("--code") + 1] if len(sys.argv) > sys.argv.index("--code") + 1 else None
+        seen, sites = mfma_result_hazards_in_code_objects(lib)
+        print("%d matrix instructions in the code objects, %d with a result register named by a vector instruction inside the hazard window" % (seen, len(sites)))
         for s in sites[:20]:
             print("  " + s)
         bad += sites
