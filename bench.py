@@ -56,6 +56,7 @@ def parse_args():
                     "them, -1 (default) = the prover state's own rule: overlap while at most two transactions are in flight")
     ap.add_argument("--chain-streams", type=int, default=3, help="--workload prove_root: shrink chains of ONE transaction proved side by side by its worker")
     ap.add_argument("--prepare", choices=["auto", "always", "never"], default="auto", help="prove_root: constraint kernels of the wide tables -- see run_prove_root")
+    ap.add_argument("--no-log23", action="store_true", help="default workload: skip the 2^23-row record (\"log23\" in the line)")
     ap.add_argument("--no-prove-root", action="store_true", help="default workload: skip the short transaction record (\"prove_root\" in the line)")
     ap.add_argument("--workload", choices=["stark_unit", "prove_root"], default="stark_unit",
                     help="stark_unit (default, BASELINE's metric): one unit STARK proof per step and worker.  prove_root: one TRANSACTION end to end "
@@ -207,13 +208,27 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
         ops.P_STATE = old
 
 
-def prove_root_record(args, timeout_s=300):
-    """The default line's transaction record, measured by a CHILD process (`bench.py --workload prove_root --inflight 8 --steps 4`) after this
-    process has finished and released its own GPU work: the headline cannot be lost to anything that happens in the transaction workload
-    (rounds 3 and 4 saw one "Memory access fault by GPU" in about twenty runs of it, DESIGN.md section 9, and a faulting process does not
-    exit by itself on this stack).  The child's stderr is passed on (the library's flight recorder writes there)."""
+def log23_record(args, timeout_s=240):
+    """north_star's target shape in the driver-run line: 2^23 rows x 93 (+40) columns, 2 units in flight x 4 steps, measured
+    by a fresh CHILD process like the transaction record -- digest check against tests/golden/proof_digests_big.json, NTT and roofline
+    figures for that size.  The headline `value` stays BASELINE's 2^20 metric."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--log-n", "23", "--inflight", "2", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--no-pcie", "--no-live-pmc", "--no-prove-root"]
+    pr, err = child_json_line(cmd, timeout_s)
+    if err is not None:
+        return err
+    rec = {k: pr.get(k) for k in ("metric", "value", "unit", "steps", "ms_per_step", "ntt", "timed_proof_check")}
+    rf = pr.get("roofline") or {}
+    rec["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch")}
+    rec["config"] = pr.get("config")
+    rec["identical_to_oracle"] = (pr.get("timed_proof_check") or {}).get("identical_to_oracle")
+    rec["note"] = "NOT the headline: north_star's 2^23-row unit, measured by a child process after the headline's own work (python bench.py --log-n 23 gives the long form)"
+    return rec
+
+
+def child_json_line(cmd, timeout_s):
+    """runs a bench child process; returns (its last JSON line, None) or (None, an error record).  The child's stderr is passed on."""
     import tempfile
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "prove_root", "--inflight", "8", "--steps", "4", "--warmup", "1", "--prepare", args.prepare]
     with tempfile.TemporaryFile() as err:
         t0 = time.perf_counter()
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=err, env=dict(os.environ, ZK_BENCH_CHILD="1"))
@@ -225,7 +240,7 @@ def prove_root_record(args, timeout_s=300):
             try:
                 out, _ = proc.communicate(timeout=15)
             except subprocess.TimeoutExpired:
-                out = b""                                  # not reaped: left behind, the line must still go out
+                out = b""
             timed_out = True
         err.seek(0)
         etxt = err.read().decode(errors="replace")
@@ -234,12 +249,23 @@ def prove_root_record(args, timeout_s=300):
         sys.stderr.flush()
     fault = "Memory access fault" in etxt or "[zk-fault]" in etxt
     if timed_out or proc.returncode != 0:
-        return {"error": ("timed out after %d s" % timeout_s) if timed_out else "child process exited with code %s" % proc.returncode, "gpu_memory_fault": fault,
-                "wall_s": round(time.perf_counter() - t0, 1), "command": " ".join(cmd[1:]), "note": "the child's stderr is in this run's stderr"}
+        return None, {"error": ("timed out after %d s" % timeout_s) if timed_out else "child process exited with code %s" % proc.returncode, "gpu_memory_fault": fault,
+                      "wall_s": round(time.perf_counter() - t0, 1), "command": " ".join(cmd[1:]), "note": "the child's stderr is in this run's stderr"}
     try:
-        pr = json.loads(out.decode().strip().splitlines()[-1])
+        return json.loads(out.decode().strip().splitlines()[-1]), None
     except Exception as e:
-        return {"error": "no JSON line from the child process: %s" % str(e)[:200], "gpu_memory_fault": fault}
+        return None, {"error": "no JSON line from the child process: %s" % str(e)[:200], "gpu_memory_fault": fault}
+
+
+def prove_root_record(args, timeout_s=300):
+    """The default line's transaction record, measured by a CHILD process (`bench.py --workload prove_root --inflight 8 --steps 4`) after this
+    process has finished and released its own GPU work: the headline cannot be lost to anything that happens in the transaction workload
+    (rounds 3 and 4 saw one "Memory access fault by GPU" in about twenty runs of it, DESIGN.md section 9, and a faulting process does not
+    exit by itself on this stack).  The child's stderr is passed on (the library's flight recorder writes there)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "prove_root", "--inflight", "8", "--steps", "4", "--warmup", "1", "--prepare", args.prepare]
+    pr, err = child_json_line(cmd, timeout_s)
+    if err is not None:
+        return err
     rec = {k: pr[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "one_tx_alone_ms", "timed_proof_check")}
     rec["config"] = pr["config"]
     rec["note"] = ("NOT the headline (`value` above is BASELINE's unit metric); measured by a child process after the headline's own work "
@@ -782,7 +808,11 @@ def main():
         # against the oracle's committed digests
         if world == 1 and args.log_n == 20 and not args.no_prove_root:
             line["prove_root"] = prove_root_record(args)
+        if world == 1 and args.log_n == 20 and not args.no_log23 and not os.environ.get("ZK_BENCH_CHILD"):
+            line["log23"] = log23_record(args)
         print(json.dumps(line))
+        if isinstance(line.get("log23"), dict) and line["log23"].get("identical_to_oracle") is False:
+            sys.exit("bench.py: the 2^23-row unit's proof differs from the oracle's committed digest")
         if isinstance(line.get("prove_root"), dict) and (line["prove_root"].get("timed_proof_check") or {}).get("identical_to_oracle") is False:
             sys.exit("bench.py: the transaction's proofs differ from the oracle's committed digests")
     if world > 1:

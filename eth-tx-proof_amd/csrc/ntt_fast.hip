@@ -7,9 +7,9 @@
 bool zk_ntt_fast_launch_dif(zk_ctx *ctx, const PassParams &p, bool row, const char *name) { return ntt_fast_launch_family<false, false>(ctx, p, row, name); }
 
 // per-position factor tables: exactly the factors the kernel would otherwise form from two-level tables at run time
-__global__ void build_pass_table_kernel(PassParams p, int dit, int store, u64 *out) {
+__global__ void build_pass_table_kernel(PassParams p, int dit, int store, u64 *out, int tab_bits) {
     size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t n = (size_t)1 << p.k;
+    size_t n = (size_t)1 << tab_bits;                         // the column, or one period 2^(W+S) of the inter-pass factors
     if (pos >= n) return;
     const int W = p.W, S = p.S;
     u32 slot = (u32)((pos >> S) & (((size_t)1 << W) - 1)), inner = (u32)(pos & (((size_t)1 << S) - 1));
@@ -25,18 +25,27 @@ __global__ void build_pass_table_kernel(PassParams p, int dit, int store, u64 *o
     }
     out[pos] = f;
 }
+// Without an input / output scale the factors of a pass depend on the position modulo 2^(W+S) only: the table is that long.  (Up to round 4
+// every table had 2^k entries and transforms beyond 2^24 were refused here -- 128 MiB per table and more -- and fell to the LDS radix-2
+// kernel.  Now the middle pass of a tall transform reads a table of 2^18 entries or so, which stays in L2; its first and last pass
+// still need 2^k entries: 2 GiB at k = 28, a few of them per shape, out of 288 GB.)
+static int pass_table_bits(const PassParams &p, bool store) {
+    const bool scaled = store ? (p.postA != nullptr || p.post_const != 0) : p.preA != nullptr;
+    return scaled ? p.k : (p.W + p.S < p.k ? p.W + p.S : p.k);
+}
 static const u64 *pass_table(zk_ctx *ctx, const PassParams &p, bool dit, bool store) {
-    if (p.k > 24) return nullptr;                                     // 128 MiB per table beyond this: keep the two-level path
+    if (p.k > 28) return nullptr;
     char key[192];
     snprintf(key, sizeof key, "%d.%d.%d.%d.%d.%p.%d.%p.%llx.%d", p.k, p.W, p.S, (int)dit, p.inverse, (const void *)p.preA, p.pre_bitrev,
              (const void *)p.postA, (unsigned long long)p.post_const, (int)store);
     auto &cache = ctx->table_cache;
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    size_t n = (size_t)1 << p.k;
+    const int bits = pass_table_bits(p, store);
+    size_t n = (size_t)1 << bits;
     u64 *t = (u64 *)ctx->alloc(n * sizeof(u64));
     if (!t) return nullptr;
-    ZK_LAUNCH(ctx, "ntt_build_table", build_pass_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p, (int)dit, (int)store, t);
+    ZK_LAUNCH(ctx, "ntt_build_table", build_pass_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p, (int)dit, (int)store, t, bits);
     cache[key] = t;
     return t;
 }
@@ -54,7 +63,7 @@ static const u64 *pass_table_cosets(zk_ctx *ctx, const PassParams &p, bool dit, 
     for (u32 h = 0; h < (1u << p.cs_bits); h++) {
         PassParams q = p;
         q.preA = pre.A[h]; q.preB = pre.B[h];
-        ZK_LAUNCH(ctx, "ntt_build_table", build_pass_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, (int)dit, 0, t + (size_t)h * n);
+        ZK_LAUNCH(ctx, "ntt_build_table", build_pass_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, q, (int)dit, 0, t + (size_t)h * n, p.k);
     }
     cache[key] = t;
     return t;
@@ -71,6 +80,9 @@ bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, con
     p.force_redo = (int)ctx->force_redo;
     bool need_load = p.preA || cs_pre || (dit && p.S > 0);
     bool need_store = !p.permute_out && ((!dit && p.S > 0) || p.postA || p.post_const);
+    // an output scale that is one constant for every position (the 1/n of an inverse transform's last pass) needs no table
+    const bool store_is_const = need_store && !(!dit && p.S > 0) && !p.postA;
+    p.load_tab_mask = p.store_tab_mask = ~0u;
     // the DIT post table is indexed by the natural output index, which equals the output position only when not permuting
     static const int use_tab = getenv("ZK_NTT_TAB") ? atoi(getenv("ZK_NTT_TAB")) : 3;       // bit0: ROW passes, bit1: TILE passes
     static const int use_colfast = getenv("ZK_NTT_COLFAST") ? atoi(getenv("ZK_NTT_COLFAST")) : 3;
@@ -80,9 +92,14 @@ bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, con
         if (cs_pre) { p.load_tab = pass_table_cosets(ctx, p, dit, *cs_pre); p.tab_sub = (size_t)1 << p.k; if (!p.load_tab) return false; }
         else if (need_load) { p.load_tab = pass_table(ctx, p, dit, false); p.tab_sub = 0; if (!p.load_tab) return false; }
     } else if (need_load && tab_on) p.load_tab = pass_table(ctx, p, dit, false);
+    if (store_is_const) { p.store_const = p.post_const; need_store = false; }
     if (need_store && tab_on) p.store_tab = pass_table(ctx, p, dit, true);
+    if (!row) {
+        if (p.load_tab && !p.cs_bits) p.load_tab_mask = (unsigned)(((size_t)1 << pass_table_bits(p, false)) - 1);
+        if (p.store_tab) p.store_tab_mask = (unsigned)(((size_t)1 << pass_table_bits(p, true)) - 1);
+    }
     // the kernel takes its per-position factors from ONE coalesced table per side or not at all: a pass whose table is not available
-    // (k > 24: 128 MiB and more per table; ZK_NTT_TAB switched off) and a permuting pass with an output scale go to the LDS radix-2 kernel
+    // (k > 28; ZK_NTT_TAB switched off) and a permuting pass with an output scale go to the LDS radix-2 kernel
     if ((need_load && !p.load_tab) || (need_store && !p.store_tab)) return false;
     if (p.permute_out && (p.postA || p.post_const)) return false;
     size_t rows_per_col = ((size_t)1 << p.k) >> p.W;

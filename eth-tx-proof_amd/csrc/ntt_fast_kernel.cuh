@@ -252,6 +252,12 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
     auto uni_off = [&](int side, int m, int q) -> size_t {
         const size_t stride = side == 0 ? p.in_stride : side == 1 ? p.out_stride : 0, sub = side == 0 ? p.in_sub : side == 1 ? p.out_sub : (side == 2 ? p.tab_sub : 0);
         if (modeB) return col_off((size_t)row032 + GM::t_uni(m, q), stride, sub) + GM::slot_uni(m, q);
+        if (!ROW && side >= 2) {
+            // a factor table may hold ONE period of 2^(W+S) positions (tall transforms): the tile's base position is reduced, the rest
+            // of the position (slot << S, t) lies below the period anyway
+            const u32 mask = side == 2 ? p.load_tab_mask : p.store_tab_mask;
+            return (side == 3 ? 0 : col_off(vcolA, stride, sub)) + (size_t)((base32 & mask) + (GM::slot_uni(m, q) << S));
+        }
         return (side == 3 ? 0 : col_off(vcolA, stride, sub)) + uni_pos(m, q);
     };
     // per-thread byte offset of mapping m on a side (the launcher has checked that it fits 32 bits)
@@ -495,11 +501,13 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
     const u32 st_thr = thr_off(1, SMAP), sttab_thr = thr_off(3, SMAP);
     const int st_lim = row_lim(SMAP);
     auto store_plain = [&](auto &fx) {
-        const bool need_mul = p.store_tab != nullptr;             // as on the load side: one table or nothing
+        const bool from_tab = p.store_tab != nullptr;             // as on the load side: one table, one constant for all, or nothing
+        const u64 sc = p.store_const;
+        const bool need_mul = from_tab || sc != 0;
         u64 f[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) f[q] = 1;
-        if (act && need_mul) {
+        for (int q = 0; q < 16; q++) f[q] = from_tab ? 1 : sc;
+        if (act && from_tab) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 if (!(st_lim > (int)GM::t_uni(SMAP, q))) continue;

@@ -27,6 +27,10 @@ struct PassParams {
     // virtual column v = (column v >> cs_bits, slot v & mask) sits at column * stride + slot * sub; its factors at load_tab + slot * tab_sub
     int cs_bits;
     size_t in_sub, out_sub, tab_sub;
+    // tall transforms (k > 24): a table whose factors repeat with period 2^(W+S) (inter-pass factors of a middle pass) holds one period,
+    // and the kernel reduces the tile's base position by this mask before it indexes the table (all ones: the table covers the column)
+    unsigned load_tab_mask, store_tab_mask;
+    u64 store_const;                // multiply every stored element by this constant instead of a table (0: none)
     unsigned n_blocks;              // register-radix kernel, persistent launch: number of tiles (0: one workgroup per tile, the grid says it)
 };
 

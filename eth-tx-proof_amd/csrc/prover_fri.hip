@@ -662,7 +662,7 @@ int32_t zk_fri_combine(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t n_oracl
 int32_t zk_fri_commit_begin(zk_ctx *ctx, const zk_stark_config *cfg, uint32_t log_n, const uint64_t *final_values, zk_fri_commit **out) {
     if (!ctx || !cfg || !final_values || !out) return ZK_ERR_INVALID_ARG;
     *out = nullptr;
-    if (cfg->rate_bits > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits < 2 || cfg->fri_arity_bits > 6 || log_n > 26 || log_n + cfg->rate_bits < cfg->cap_height)
+    if (cfg->rate_bits > 4 || cfg->cap_height > 8 || cfg->fri_arity_bits < 2 || cfg->fri_arity_bits > 6 || log_n > 28 || log_n + cfg->rate_bits < cfg->cap_height)
         return ctx->fail(ZK_ERR_INVALID_ARG, "fri commit: unsupported FRI parameters");
     if (!zk_fri_reduction_ok(*cfg, log_n)) return ctx->fail(ZK_ERR_INVALID_ARG, "fri commit: the reduction strategy does not fit this size (upstream panics)");
     hipSetDevice(ctx->device);

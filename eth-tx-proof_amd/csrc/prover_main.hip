@@ -126,7 +126,7 @@ static int32_t prove_tables_impl(zk_ctx *ctx, const zk_stark_config *cfgp, uint3
     if (cfg.num_challenges == 0 || cfg.num_challenges > 4 || cfg.rate_bits != 1 || cfg.cap_height > 8 || cfg.fri_arity_bits < 2 || cfg.fri_arity_bits > 6)
         return ctx->fail(ZK_ERR_INVALID_ARG, "prove: unsupported StarkConfig");
     for (u32 t = 0; t < nt; t++) {
-        if (!tables[t].air || !tables[t].trace || tables[t].log_n > 26 || tables[t].log_n + cfg.rate_bits < cfg.cap_height)
+        if (!tables[t].air || !tables[t].trace || tables[t].log_n > 28 || tables[t].log_n + cfg.rate_bits < cfg.cap_height)
             return ctx->fail(ZK_ERR_INVALID_ARG, "prove: bad table");
         if (!zk_fri_reduction_ok(cfg, tables[t].log_n)) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: the FRI reduction strategy does not fit this table size (upstream panics)");
         if (zk_air_validate(tables[t].air, cfg.num_challenges) != ZK_OK) return ctx->fail(ZK_ERR_INVALID_ARG, "prove: malformed AIR (zk_air_validate)");

@@ -629,6 +629,36 @@ extern "C" int32_t zk_prover_state_stats(uint64_t *compiled, uint64_t *loaded_fr
 // the file's key adds the generator version, the field header, the GPU architecture and the hiprtc version, so a library, driver or
 // hardware change never loads a stale image; an image that fails to load is deleted and rebuilt.  settle_args: a zeroed parameter block
 // (L = 0: every thread returns at once) for the first launch of the freshly loaded code object.
+// the on-disk key of a kernel: what its source depends on + generator version, field header, GPU architecture name, hiprtc version
+static std::string jit_disk_key(const std::string &base_key, const char *gcn_arch_name) {
+    std::string disk_key = base_key;
+    const u64 ver[2] = {7 /* generator version */, fnv1a(GL64_SRC)};
+    disk_key.append((const char *)ver, sizeof ver);
+    if (gcn_arch_name) disk_key.append(gcn_arch_name);
+    int rmaj = 0, rmin = 0;
+    if (hiprtcVersion(&rmaj, &rmin) == HIPRTC_SUCCESS) { const int rv[2] = {rmaj, rmin}; disk_key.append((const char *)rv, sizeof rv); }
+    return disk_key;
+}
+// hiprtc for gfx950 (needs no device); on failure `log` holds the compiler's words
+static bool jit_hiprtc(const std::string &src, std::vector<char> &image, std::string &log) {
+    hiprtcProgram prog;
+    const char *hs[] = {GL64_SRC}, *hn[] = {"gl64.cuh"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "quotient_jit.hip", 1, hs, hn) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return false; }
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
+        log.assign(ls + 1, 0); hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return false;
+    }
+    size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+    image.resize(cs);
+    hiprtcGetCode(prog, image.data());
+    hiprtcDestroyProgram(&prog);
+    return true;
+}
+
 static int32_t jit_compile_cached(zk_ctx *ctx, const std::string &base_key, bool may_compile, const std::function<std::string()> &gen, const char *kname,
                                   void *settle_args, JitKernel &k) {
     std::string key = base_key;
@@ -637,14 +667,10 @@ static int32_t jit_compile_cached(zk_ctx *ctx, const std::string &base_key, bool
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { k = it->second; return ZK_OK; }
     if (!may_compile) { k = JitKernel(); return ZK_OK; }
-    std::string disk_key = base_key;
+    std::string disk_key;
     {
-        const u64 ver[2] = {7 /* generator version */, fnv1a(GL64_SRC)};
-        disk_key.append((const char *)ver, sizeof ver);
         hipDeviceProp_t pr;
-        if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) disk_key.append(pr.gcnArchName);
-        int rmaj = 0, rmin = 0;
-        if (hiprtcVersion(&rmaj, &rmin) == HIPRTC_SUCCESS) { const int rv[2] = {rmaj, rmin}; disk_key.append((const char *)rv, sizeof rv); }
+        disk_key = jit_disk_key(base_key, hipGetDeviceProperties(&pr, ctx->device) == hipSuccess ? pr.gcnArchName : nullptr);
     }
     for (int attempt = 0; attempt < 2; attempt++) {
         k = JitKernel();
@@ -655,22 +681,8 @@ static int32_t jit_compile_cached(zk_ctx *ctx, const std::string &base_key, bool
             if (const char *dump = getenv("ZK_QUOTIENT_JIT_DUMP")) {       // debugging aid: the generated source, for offline inspection
                 if (FILE *f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
             }
-            hiprtcProgram prog;
-            const char *hs[] = {GL64_SRC}, *hn[] = {"gl64.cuh"};
-            if (hiprtcCreateProgram(&prog, src.c_str(), "quotient_jit.hip", 1, hs, hn) != HIPRTC_SUCCESS)
-                return ctx->fail(ZK_ERR_HIP, "quotient jit: hiprtcCreateProgram failed");
-            const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-            hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
-            if (r != HIPRTC_SUCCESS) {
-                size_t ls = 0; hiprtcGetProgramLogSize(prog, &ls);
-                std::string log(ls + 1, 0); hiprtcGetProgramLog(prog, &log[0]);
-                hiprtcDestroyProgram(&prog);
-                return ctx->fail(ZK_ERR_HIP, ("quotient jit: compile failed: " + log.substr(0, 400)).c_str());
-            }
-            size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
-            k.image->resize(cs);
-            hiprtcGetCode(prog, k.image->data());
-            hiprtcDestroyProgram(&prog);
+            std::string log;
+            if (!jit_hiprtc(src, *k.image, log)) return ctx->fail(ZK_ERR_HIP, ("quotient jit: compile failed: " + log.substr(0, 400)).c_str());
             co_store(disk_key, *k.image);
             g_n_compiled++;
         }
@@ -741,6 +753,43 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
     }
     std::lock_guard<std::mutex> lk(g_qmu);
     g_qcache[qkey] = out;
+    return ZK_OK;
+}
+
+// The prover-state files WITHOUT a GPU (VERDICT r4 #5a): __graft_entry__.build() -- and whoever packages the library -- writes the compiled
+// constraint kernels of the given AIRs into the prover-state directory, so that a clean clone proves its first transaction with compiled
+// kernels instead of interpreting (or spending 100 s in hiprtc inside a proof).  The same source, key and file format as
+// zk_prover_state_prepare; gcn_arch_name is what hipGetDeviceProperties reports on the target ("gfx950:sramecc+:xnack-" on MI355X) and is
+// part of the key: a file written for another target is simply not found.  Tables whose kernel was built with the library are skipped.
+extern "C" int32_t zk_prover_state_build_offline(const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables, const char *gcn_arch_name,
+                                                 uint64_t *n_built, uint64_t *n_present) {
+    if (!cfg || (!tables && n_tables) || !gcn_arch_name) return ZK_ERR_INVALID_ARG;
+    uint64_t built = 0, present = 0;
+    for (uint32_t t = 0; t < n_tables; t++) {
+        const zk_air *air = tables[t].air;
+        if (!air || zk_air_validate(air, cfg->num_challenges) != ZK_OK) return ZK_ERR_INVALID_ARG;
+        const u32 nch = cfg->num_challenges, A = zk_air_n_aux(air, nch), C = air->n_trace_cols;
+        if (zk_quotient_aot_lookup(fnv1a(air_key(air, C, A, nch, cfg->rate_bits)))) continue;
+        std::string key = air_key(air, C, A, nch, cfg->rate_bits);
+        if (air->n_instrs >= seg_min()) {                       // exactly jit_get's key of a kernel sequence
+            const u32 hdr[4] = {0x53454751u /* "SEGQ" */, seg_len(), seg_len() / 4, QJIT_FENCE};
+            key.append((const char *)hdr, sizeof hdr);
+        }
+        const std::string disk_key = jit_disk_key(key, gcn_arch_name);
+        std::vector<char> image;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if (cache_dir().empty()) return ZK_ERR_INVALID_ARG;
+            if (co_load(disk_key, image)) { present++; continue; }
+        }
+        std::string log;
+        if (!jit_hiprtc(generate(air, C, A, nch, cfg->rate_bits), image, log)) { fprintf(stderr, "[zkgl] offline build: %s\n", log.substr(0, 600).c_str()); return ZK_ERR_HIP; }
+        std::lock_guard<std::mutex> lk(g_mu);
+        co_store(disk_key, image);
+        built++;
+    }
+    if (n_built) *n_built = built;
+    if (n_present) *n_present = present;
     return ZK_OK;
 }
 

@@ -494,6 +494,22 @@ def prover_state_cache_dir(path):
     lib().zk_prover_state_cache_dir(None if path is None else str(path).encode())
 
 
+MI355X_ARCH_NAME = "gfx950:sramecc+:xnack-"          # hipDeviceProp_t::gcnArchName on MI355X: part of a prover-state file's key
+
+
+def prover_state_build_offline(cfg, progs, arch_name=MI355X_ARCH_NAME):
+    """zk_prover_state_build_offline: compile the constraint kernels of these AIR programs into the prover-state directory without a GPU;
+    returns (files written, files already there)"""
+    arr = (Table * len(progs))()
+    for i, p in enumerate(progs):
+        arr[i].air = C.cast(p.ref, C.c_void_p)
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    rc = lib().zk_prover_state_build_offline(C.byref(cfg), C.c_uint32(len(progs)), arr, arch_name.encode(), C.byref(a), C.byref(b))
+    if rc != 0:
+        raise RuntimeError("zk_prover_state_build_offline failed with %d" % rc)
+    return a.value, b.value
+
+
 def prover_state_stats():
     """(kernels compiled by hiprtc, kernels loaded from disk) in this process"""
     a, b = C.c_uint64(0), C.c_uint64(0)

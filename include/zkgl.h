@@ -347,6 +347,12 @@ int32_t zk_prover_state_prepare(zk_ctx *ctx, const zk_stark_config *cfg, uint32_
  * zk_prover_state_stats: kernels compiled by hiprtc / loaded from disk so far in this process. */
 int32_t zk_prover_state_cache_dir(const char *dir);
 int32_t zk_prover_state_stats(uint64_t *compiled, uint64_t *loaded_from_disk);
+/* The same files written WITHOUT a GPU or a context (packaging / build step): the constraint kernels of the given AIRs (only `air` of every
+ * table is read) are compiled by hiprtc for gfx950 and stored in the cache directory under the key a process on the target would look up.
+ * gcn_arch_name: what hipGetDeviceProperties reports there ("gfx950:sramecc+:xnack-" on MI355X).  n_built / n_present (optional): files
+ * written / found already there.  Kernels that were built with the library are skipped. */
+int32_t zk_prover_state_build_offline(const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables, const char *gcn_arch_name,
+                                      uint64_t *n_built, uint64_t *n_present);
 /* Build-time half of the same idea (upstream's constraints are Rust code monomorphised when the prover is built): the HIP source of
  * the constraint kernel of one AIR and the hash that names it.  Host only (no context, no GPU); tools/gen_aot_quotient.py writes
  * the kernels of the AIRs known at build time into csrc/prover_quotient_aot.hip, which is compiled with the library.

@@ -11,6 +11,8 @@ u64p = C.POINTER(C.c_uint64)
 
 
 def build(force=False):
+    if os.environ.get("ORC_LIB"):                     # the sanitizer build (make -C oracle asan), chosen by the test that preloads libasan
+        return os.environ["ORC_LIB"]
     so = os.path.join(_here, "liboracle.so")
     srcs = [os.path.join(_here, f) for f in ("prims.c", "stark.c", "verify.c", "plonk.c", "gl.h", "oracle.h", "poseidon_constants.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

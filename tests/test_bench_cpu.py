@@ -70,3 +70,6 @@ def test_a_failing_transaction_child_becomes_an_error_record_not_a_lost_line(cap
     assert set(rec) >= {"error", "gpu_memory_fault", "command"} and "exited with code" in rec["error"] and rec["gpu_memory_fault"] is False
     assert "--workload prove_root" in rec["command"]
     assert capfd.readouterr().err.strip(), "the child's stderr was not passed on"
+    # the 2^23-row record goes through the same child mechanism
+    rec = bench.log23_record(types.SimpleNamespace(), timeout_s=240)
+    assert set(rec) >= {"error", "gpu_memory_fault", "command"} and "--log-n 23" in rec["command"]

@@ -41,6 +41,35 @@ def test_big_unit_proof_hashes_to_the_oracles_digest(ctx, ent):
     assert _sha(proof) == ent["sha256"], "GPU proof of the 2^%d-row unit differs from the oracle's (committed digest)" % ent["log_n"]
 
 
+TALL = GOLD.get("tall_unit_proofs", [])
+TALL_SHAPES = [(24, 93, 19), (25, 21, 5), (26, 21, 5)]
+
+
+@pytest.mark.parametrize("log_n,n_cols,n_helpers", TALL_SHAPES, ids=lambda v: str(v))
+def test_tall_unit_proof_is_accepted_by_the_oracles_verifier_and_hashes_to_its_digest(ctx, log_n, n_cols, n_helpers):
+    """Tables above 2^23 rows: the reference's default ranges are Cpu 12..25, Arithmetic 16..23, Memory 17..28
+    (/root/reference/common/src/prover_state/circuit.rs:76-86).  A Cpu-shaped 2^24 x 93 (+40 aux) unit and Memory-shaped 2^25 / 2^26 x 21
+    (+12 aux) units are proved on one card.  The oracle's PROVER needs ~6 GB of host memory and minutes per 2^20 x 133 rows, so here the
+    oracle's VERIFIER (which needs no trace: caps, openings, the constraint identity at zeta, every FRI query) accepts the proof words;
+    where the oracle's proof of the same input was computed once (tools/gen_golden_big.py --tall), its committed sha256 must match too."""
+    import orc
+    cfg = E.standard_fast_config()
+    prog = air.cpu_like_air(n_cols, n_helpers)
+    seed = 0x7A110000 + 1000 * log_n + n_cols
+    d, pub = zl.synth_trace_dev(ctx, n_cols, log_n, seed)
+    try:
+        proof = zl.prove_tables(ctx, cfg, [(prog, log_n, d, pub)])
+    finally:
+        ctx.dev_free(d)
+    assert proof.size == orc.proof_size_words(cfg, [(prog, log_n, None, pub)])
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0, "the oracle's verifier rejects the GPU proof of the 2^%d x %d unit" % (log_n, n_cols)
+    bad = proof.copy(); bad[proof.size // 2] ^= np.uint64(1)
+    assert orc.verify(cfg, [(prog, log_n, None, pub)], bad) != 0
+    for ent in TALL:
+        if (ent["log_n"], ent["n_cols"], ent["n_helpers"], ent["seed"]) == (log_n, n_cols, n_helpers, seed):
+            assert proof.size == ent["words"] and _sha(proof) == ent["sha256"], "GPU proof differs from the oracle's (committed digest)"
+
+
 @pytest.mark.parametrize("ent", GOLD["cfg4_units"], ids=lambda e: "cfg4")
 def test_seven_table_unit_hashes_to_the_oracles_digest(ctx, ent):
     cfg = E.standard_fast_config()

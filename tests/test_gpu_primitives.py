@@ -65,6 +65,53 @@ def test_ntt_forward_inverse_coset(ctx, orc, log_n):
     assert (ctx.ntt(cf, inverse=True, shift=G) == v % np.uint64(P)).all()
 
 
+@pytest.mark.parametrize("log_n", [22, 25, 26])
+def test_ntt_tall_transforms(ctx, orc, log_n):
+    """Transforms beyond 2^24 (the reference's default table ranges reach 2^25 for Cpu and 2^28 for Memory,
+    /root/reference/common/src/prover_state/circuit.rs:76-86): three digit passes through the register-radix kernel -- the middle pass
+    reads ONE PERIOD of its inter-pass factors (a table of 2^(W+S) entries), the 1/n of the inverse is a constant, not a table.  Up to round 4
+    these sizes fell to the LDS radix-2 kernel.  One column against the oracle's transform, and the round trip."""
+    rng = np.random.default_rng(300 + log_n)
+    v = field_rand(rng, (1, 1 << log_n))
+    v[0, :8] = EDGE
+    f = ctx.ntt(v)
+    assert (f == orc.fft(v)).all()
+    assert (ctx.ntt(f, inverse=True) == v % np.uint64(P)).all()
+    if log_n <= 25:
+        cf = ctx.ntt(v, shift=G)
+        assert (ctx.ntt(cf, inverse=True, shift=G) == v % np.uint64(P)).all()
+        if log_n <= 22:
+            assert (cf == orc.fft(v, shift=G)).all()
+
+
+@pytest.mark.parametrize("log_n,ncols", [(22, 3), (25, 2)])
+def test_commit_of_tall_columns_register_radix_equals_lds_radix2_and_oracle(zk, orc, monkeypatch, log_n, ncols):
+    """from_values at three digit passes (inverse DIF, then the coset DIT passes with the permuted last store): the register-radix passes
+    against the LDS radix-2 kernel (ZK_NTT_SLOW=1: every pass the old way) -- same cap, same opened rows -- and at 2^22 against the
+    oracle's commitment."""
+    rng = np.random.default_rng(17 * log_n)
+    v = field_rand(rng, (ncols, 1 << log_n))
+    c = zk.Context(0)
+    try:
+        b = c.batch_from_values(v, rate_bits=1, cap_height=4)
+        cap = b.cap.copy()
+        idx = [0, 1, 12345, (1 << log_n) + 77, (2 << log_n) - 1]
+        rows = [b.prove(i).copy() for i in idx]
+        b.free()
+        monkeypatch.setenv("ZK_NTT_SLOW", "1")
+        b2 = c.batch_from_values(v, rate_bits=1, cap_height=4)
+        assert (b2.cap == cap).all()
+        for i, r in zip(idx, rows):
+            assert (b2.prove(i) == r).all()
+        b2.free()
+        monkeypatch.delenv("ZK_NTT_SLOW")
+        if log_n <= 22:
+            o = orc.Batch(v, rate_bits=1, cap_height=4)
+            assert (o.cap == cap).all()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("log_n,r", [(4, 1), (6, 3), (10, 1), (12, 2), (14, 3), (16, 1), (5, 5), (3, 0)])
 def test_ntt_zero_factor(ctx, orc, log_n, r):
     """zk_ntt_batch_opts: upstream's `zero_factor` of fft_with_options / coset_fft_with_options / ifft_with_options -- the transform of

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--plonk", default="")
     ap.add_argument("--root", action="store_true")
     ap.add_argument("--merge", action="store_true")
+    ap.add_argument("--tall", default="", help="log_n:n_cols:n_helpers[,...] -- units above 2^23 rows (tests/test_gpu_big.py TALL_SHAPES), one oracle proof each")
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--threads", type=int, default=0)
     args = ap.parse_args()
@@ -66,7 +67,7 @@ def main():
                    "made by tools/gen_golden_big.py", "oracle_threads": threads, "unit_proofs": [], "cfg4_units": [], "plonk_proofs": [], "prove_root": []}
     if args.merge and os.path.exists(args.out):
         old = json.load(open(args.out))
-        for k in ("unit_proofs", "cfg4_units", "plonk_proofs", "prove_root"):
+        for k in ("unit_proofs", "cfg4_units", "plonk_proofs", "prove_root", "tall_unit_proofs"):
             out[k] = old.get(k, [])
         if args.sizes:
             out["unit_proofs"] = []
@@ -103,6 +104,28 @@ def main():
                 log("   gpu identical: %s" % ent["gpu_identical"])
             out["unit_proofs"].append(ent)
             flush()
+    for spec in [x for x in args.tall.split(",") if x]:
+        log_n, n_cols, n_helpers = [int(v) for v in spec.split(":")]
+        seed = 0x7A110000 + 1000 * log_n + n_cols
+        prog = air.cpu_like_air(n_cols, n_helpers)
+        t0 = time.time()
+        tr, pub = orc.synth_trace(n_cols, log_n, seed)
+        rc, ref = orc.prove(cfg, [(prog, log_n, tr, pub)])
+        t_or = time.time() - t0
+        assert rc == 0
+        del tr
+        ent = {"n_cols": n_cols, "n_helpers": n_helpers, "log_n": log_n, "seed": seed, "words": int(ref.size), "sha256": sha(ref), "oracle_seconds": round(t_or, 1)}
+        log("tall 2^%d x %d seed %#x: oracle %.1f s, %d words" % (log_n, n_cols, seed, t_or, ref.size))
+        if ctx is not None:
+            d, gpub = zl.synth_trace_dev(ctx, n_cols, log_n, seed)
+            g = zl.prove_tables(ctx, cfg, [(prog, log_n, d, gpub)])
+            ctx.dev_free(d)
+            ent["gpu_identical"] = bool(g.size == ref.size and (g == ref).all())
+            bad += 0 if ent["gpu_identical"] else 1
+            log("   gpu identical: %s" % ent["gpu_identical"])
+        out.setdefault("tall_unit_proofs", [])
+        out["tall_unit_proofs"] = [e for e in out["tall_unit_proofs"] if (e["log_n"], e["n_cols"]) != (log_n, n_cols)] + [ent]
+        flush()
     if args.cfg4:
         items, gitems = [], []
         t0 = time.time()

@@ -60,7 +60,7 @@ int main(int argc, char **argv) {
     CK(hipDeviceSynchronize());
     hipStream_t st; CK(hipStreamCreate(&st));
     PassParams b = {};
-    b.k = k; b.W = 10; b.TL = 3; b.n_cols = n_cols; b.tw_full = rw; b.col_group = col_group;
+    b.k = k; b.W = 10; b.TL = 3; b.n_cols = n_cols; b.tw_full = rw; b.col_group = col_group; b.load_tab_mask = b.store_tab_mask = ~0u;
     struct { const char *name; float ms; } res[4];
     { PassParams p = b; p.in = in; p.in_stride = n; p.out = mid; p.out_stride = n; p.S = 10; p.inverse = 1; p.canon_in = 1; p.store_tab = tab; p.col_fast = 2;
       res[0] = {"inverse DIF pass 1 (TILE, inter-pass factors at the store)", run<false, false, true>(p, reps, st)}; }
