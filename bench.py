@@ -117,64 +117,87 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
         root0, _, all0 = ops.prove_root(u0)        # builds every circuit's prover data: start-up work too
         split = {"stark_s": 0.0, "shrink_s": 0.0, "root_s": 0.0}
         reps = 3
+        ws0 = (rec.witness_standin_seconds, rec.witness_standin_rows)
         for _ in range(reps):
             tm = {}
             r, _, _ = ops.prove_root(u0, tm)
             assert np.array_equal(r, root0)
             for k in split:
                 split[k] += tm[k] / reps
+        ws_ms_per_tx, ws_rows_per_tx = (rec.witness_standin_seconds - ws0[0]) * 1e3 / reps, (rec.witness_standin_rows - ws0[1]) // reps
+        # the same without the CPU stand-in for per-proof witness generation (round 4's number): plonk.SyntheticRecursion.witness_standin
+        standin_default = rec.witness_standin
+        alone_without = None
+        if standin_default:
+            rec.witness_standin = False
+            alone_without = 0.0
+            for _ in range(reps):
+                tm = {}
+                r, _, _ = ops.prove_root(u0, tm)
+                assert np.array_equal(r, root0)
+                alone_without += sum(tm[k] for k in split) / reps
+            rec.witness_standin = True
         ctx0.profile(True); ctx0.profile_reset()
         ops.prove_root(u0)
         rep = ctx0.profile_report()
         ctx0.profile(False)
-        errs = []
-        go, done = threading.Barrier(inflight + 1), threading.Barrier(inflight + 1)
+        def timed_region():
+            """`inflight` worker threads, one context and one transaction each: warm-up, then `steps` transactions per worker between two barriers"""
+            errs = []
+            go, done = threading.Barrier(inflight + 1), threading.Barrier(inflight + 1)
 
-        def worker(s):
+            def worker(s):
+                try:
+                    u = unit(st.ctx())
+                    for _ in range(max(1, warmup)):
+                        ops.prove_root(u)
+                    go.wait()
+                    for _ in range(steps):
+                        r = ops.prove_root(u)[0]
+                    if not np.array_equal(r, root0):
+                        raise RuntimeError("worker %d: another root proof than the first unit's" % s)
+                    done.wait()
+                except threading.BrokenBarrierError:
+                    pass                               # another worker failed first
+                except Exception as e:
+                    import traceback
+                    errs.append(e)
+                    sys.stderr.write("[bench] transaction worker %d failed: %r\n%s" % (s, e, traceback.format_exc()))
+                    sys.stderr.flush()
+                    go.abort(); done.abort()
+                finally:
+                    st.drop_ctx()
+            th = [threading.Thread(target=worker, args=(s,)) for s in range(inflight)]
+            for t in th:
+                t.start()
             try:
-                u = unit(st.ctx())
-                for _ in range(max(1, warmup)):
-                    ops.prove_root(u)
                 go.wait()
-                for _ in range(steps):
-                    r = ops.prove_root(u)[0]
-                if not np.array_equal(r, root0):
-                    raise RuntimeError("worker %d: another root proof than the first unit's" % s)
+            except threading.BrokenBarrierError:
+                pass                                   # a worker failed during its warm-up: its error is raised below
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if os.environ.get("ZK_VA_PROBE"):          # debug: the runtime's view of the address windows the unexplained GPU faults named, with every context alive and busy
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import va_probe
+                time.sleep(0.2)
+                va_probe.probe("transactions in flight")
+            try:
                 done.wait()
             except threading.BrokenBarrierError:
-                pass                               # another worker failed first
-            except Exception as e:
-                import traceback
-                errs.append(e)
-                sys.stderr.write("[bench] transaction worker %d failed: %r\n%s" % (s, e, traceback.format_exc()))
-                sys.stderr.flush()
-                go.abort(); done.abort()
-            finally:
-                st.drop_ctx()
-        th = [threading.Thread(target=worker, args=(s,)) for s in range(inflight)]
-        for t in th:
-            t.start()
-        try:
-            go.wait()
-        except threading.BrokenBarrierError:
-            pass                                   # a worker failed during its warm-up: its error is raised below
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if os.environ.get("ZK_VA_PROBE"):          # debug: the runtime's view of the address windows the unexplained GPU faults named, with every context alive and busy
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import va_probe
-            time.sleep(0.2)
-            va_probe.probe("transactions in flight")
-        try:
-            done.wait()
-        except threading.BrokenBarrierError:
-            pass                                   # a worker failed: what it raised is in errs
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
+                pass                                   # a worker failed: what it raised is in errs
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+            return dt
+        dt = timed_region()
+        dt_without = None
+        if standin_default:
+            rec.witness_standin = False
+            dt_without = timed_region()
+            rec.witness_standin = True
         n_tx = steps * inflight
         sha = lambda w: hashlib.sha256(np.ascontiguousarray(w, dtype=np.uint64).tobytes()).hexdigest()
         gold = golden_prove_root()
@@ -185,6 +208,7 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
         kern = {k: {"launches_per_tx": l, "ms_per_tx_alone": round(ms, 3)} for k, (l, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1])[:14] if not k.startswith("phase: ")}
         return {
             "metric": "transaction root proofs/sec (prove_root: 7 table STARKs + shrink chains + root proof)", "value": n_tx / dt, "unit": "tx/s", "n_gpus": 1,
+            "value_without_witness_generation": (n_tx / dt_without) if dt_without else None,
             "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 (Goldilocks field)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3] end to end: seven tables (log sizes %s, widths %s) on one challenger, shrink chains %s (degree bits), "
@@ -196,10 +220,13 @@ def run_prove_root(inflight, steps, warmup, chain_streams=3, chain_overlap=-1, p
                        else "bytecode interpreter (no prover-state files in %s and no compile inside a bench run: python bench.py --workload prove_root --prepare always writes them)" % os.path.relpath(PROVER_STATE_DIR, ROOT),
                        "fiat_shamir_sponge": "device-resident (one-wave kernel) in the timed region; on a host thread (zk_ctx_set_host_transcript) while at most 2 transactions are in flight, "
                                              "i.e. for one_tx_alone_ms -- the same rule as the chain overlap; identical proof words either way",
-                       "recursion_witnesses": "PRECOMPUTED: one satisfying witness per stand-in circuit, held in pinned host memory, PublicInputGate cells rewritten per proof -- upstream runs plonky2's "
-                                              "witness generators on the CPU for every proof; that work is NOT in this number (SURVEY.md 8f-2 leaves generators on the CPU)",
+                       "recursion_witnesses": ("CPU STAND-IN for per-proof witness generation inside every transaction (zk_host_plonk_witness_recompute: the cells of plonky2's PoseidonGenerator / "
+                                               "ArithmeticBaseGenerator recomputed from the rows' inputs in the proving threads: %d gate rows = %.1f ms of CPU per transaction); `value_without_witness_generation` / "
+                                               "`one_tx_alone_ms.total_without_witness_generation` = round 4's form (one precomputed witness per circuit).  The real circuits' generators are absent (SURVEY A10): a "
+                                               "cost model, not upstream's code" % (ws_rows_per_tx, ws_ms_per_tx))
+                                              if standin_default else "PRECOMPUTED: one satisfying witness per stand-in circuit (ZK_WITNESS_STANDIN=0); upstream's per-proof witness generators are NOT in this number",
                        "parallelism": "independent transactions, 1 GPU"},
-            "one_tx_alone_ms": {"total": sum(split.values()) * 1e3, "stark_proofs": split["stark_s"] * 1e3,
+            "one_tx_alone_ms": {"total": sum(split.values()) * 1e3, "total_without_witness_generation": alone_without * 1e3 if alone_without is not None else None, "stark_proofs": split["stark_s"] * 1e3,
                                 "shrink_chains_%d_plonk_proofs" % sum(len(c) for c in chains): split["shrink_s"] * 1e3, "root_proof": split["root_s"] * 1e3},
             "timed_proof_check": check, "kernels_one_tx_alone": kern}
     finally:
@@ -266,7 +293,7 @@ def prove_root_record(args, timeout_s=300):
     pr, err = child_json_line(cmd, timeout_s)
     if err is not None:
         return err
-    rec = {k: pr[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "one_tx_alone_ms", "timed_proof_check")}
+    rec = {k: pr.get(k) for k in ("metric", "value", "value_without_witness_generation", "unit", "steps", "ms_per_step", "one_tx_alone_ms", "timed_proof_check")}
     rec["config"] = pr["config"]
     rec["note"] = ("NOT the headline (`value` above is BASELINE's unit metric); measured by a child process after the headline's own work "
                    "(python bench.py --workload prove_root gives the long form)")

@@ -39,6 +39,8 @@ void *zk_ctx::alloc(size_t bytes) {
             const size_t B = ((size_t)va + k_lo * gran + G4 - 1) & ~(G4 - 1);
             void *m = (void *)(B - k_lo * gran);
             if (hipMemCreate(&h, mapped, &prop, 0) != hipSuccess || hipMemMap(m, mapped, 0, h, 0) != hipSuccess || hipMemSetAccess(m, mapped, &ad, 1) != hipSuccess) {
+                (void)hipGetLastError();
+                hipMemAddressFree(va, G4 + mapped);            // the reservation does not outlive a failed mapping
                 last_error = "straddle allocation failed"; return nullptr;
             }
             p = (void *)(B - half_lo);
@@ -337,7 +339,7 @@ int32_t zk_ctx_destroy(zk_ctx *c) {
     if (c->side) { zk_ctx_destroy(c->side); c->side = nullptr; }
     c->prof_flush();
     for (auto e : c->event_pool) hipEventDestroy(e);
-    ZK_ALLOC_TRACE("ctx-destroy", c, c->block_size.size());
+    if (zk_alloc_trace_on()) fprintf(stderr, "[zk-alloc] ctx-destroy %p %zu blocks\n", (void *)c, c->block_size.size());     // stderr only: not a block of the flight recorder
     if (!c->efence) for (auto &kv : c->block_size) { ZK_ALLOC_TRACE("free-dev-block", kv.first, kv.second); hipFree(kv.first); }
     ZK_ALLOC_TRACE("free-dev-err-word", c->d_err, 256); hipFree(c->d_err);
     if (c->h_stage) { ZK_ALLOC_TRACE("free-host-stage", c->h_stage, 0); hipHostFree(c->h_stage); }

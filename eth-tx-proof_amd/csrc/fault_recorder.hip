@@ -185,11 +185,15 @@ void zk_fault_note_block(const char *tag, const void *p, size_t n) {
 
 void zk_fault_register_ctx(zk_ctx *c) {
     { std::lock_guard<std::mutex> lk(g_mu); g_ctxs.push_back(c); }
-    if (g_registered.exchange(1)) return;
+    // g_registered: 0 = not tried yet, 1 = the handler is installed, -1 = switched off or the registration failed (zk_debug_fault_report says
+    // "registered" only for 1: ADVICE r4)
+    static std::atomic<int> tried{0};
+    if (tried.exchange(1)) return;
     const char *e = getenv("ZK_FAULT_RECORDER");
-    if (e && atoi(e) == 0) return;
+    if (e && atoi(e) == 0) { g_registered.store(-1); return; }
     // the HIP runtime has initialised HSA by the time a context exists
-    if (hsa_amd_register_system_event_handler(on_event, nullptr) != HSA_STATUS_SUCCESS && getenv("ZK_ALLOC_TRACE")) fprintf(stderr, "[zk-fault] could not register the event handler\n");
+    if (hsa_amd_register_system_event_handler(on_event, nullptr) == HSA_STATUS_SUCCESS) g_registered.store(1);
+    else { g_registered.store(-1); if (getenv("ZK_ALLOC_TRACE")) fprintf(stderr, "[zk-fault] could not register the event handler\n"); }
 }
 void zk_fault_unregister_ctx(zk_ctx *c) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -208,5 +212,5 @@ extern "C" int32_t zk_debug_fault_report(uint64_t addr) {
     g_dry_run = true;
     on_event(&ev, nullptr);
     g_dry_run = false;
-    return g_registered.load() ? 0 : -1;
+    return g_registered.load() == 1 ? 0 : -1;
 }

@@ -536,8 +536,14 @@ int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32
     // a segmented program hands accumulators and live registers from kernel to kernel through a state buffer [half][slot][point]
     u64 *state = nullptr;
     if (k.fns.size() > 1) {
+        // 2 * n_state * L words: about 110 MB for the widest zkEVM table at L = 2^18, several GB for a wide AIR at L >= 2^23.  When the
+        // device cannot give that, the proof must not fail for it: the bytecode interpreter needs no such buffer
         state = (u64 *)ctx->alloc((size_t)2 * k.n_state * p.L * sizeof(u64));
-        if (!state) return ctx->fail(ZK_ERR_OOM, "quotient jit: state buffer of the kernel sequence");
+        if (!state) {
+            static bool told = false;
+            if (!told) { told = true; fprintf(stderr, "[zkgl] no memory for the %.1f GB state buffer of a constraint-kernel sequence: this table is evaluated by the interpreter\n", 2.0 * k.n_state * p.L * 8e-9); }
+            return ZK_JIT_UNAVAILABLE;
+        }
     }
     p.state = state;
     void *args[] = {&p};
@@ -745,7 +751,9 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
         char nm[64]; snprintf(nm, sizeof nm, "quotient_jit_%u", j);
         hipFunction_t f = nullptr;
         if (hipModuleGetFunction(&f, k.mod, nm) != hipSuccess) { out = QuotKernels(); return ctx->fail(ZK_ERR_HIP, "quotient jit: a kernel of the sequence is missing from the module"); }
-        // as for the first kernel (jit_compile_cached): no scratch if so required, and one settling launch with L = 0
+        // as for the first kernel (jit_compile_cached): no scratch if so required.  (No settling launch of its own: the module was loaded
+        // and its first kernel launched and waited for in jit_compile_cached -- what the settling launch is about is the freshly loaded
+        // code object, not the individual entry point.)
         static const bool no_scratch = getenv("ZK_QUOTIENT_JIT_NO_SCRATCH") && atoi(getenv("ZK_QUOTIENT_JIT_NO_SCRATCH"));
         int scratch = 0;
         if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) != hipSuccess || (no_scratch && scratch > 0)) { out = QuotKernels(); return ZK_OK; }

@@ -11,6 +11,8 @@ a circuit here is data: constant/selector columns, the routed-wire permutation a
     wires with the result in an advice wire, and the degree-7 s-box  a^7 - e  (e an advice wire): degree 8 with the selector.
 """
 import ctypes as C
+import os
+import time
 
 import numpy as np
 
@@ -168,7 +170,7 @@ class SyntheticRecursion:
 
     ROOT_BITS, AGG_BITS, BLOCK_BITS, SHRINK_BITS, THRESHOLD_DEGREE_BITS = 15, 14, 14, 12, 13
 
-    def __init__(self, cfg=None, degree_bits=None, seed=1, size_shift=0, threshold=None, degree_bits_ranges=None, stark_cfg=None):
+    def __init__(self, cfg=None, degree_bits=None, seed=1, size_shift=0, threshold=None, degree_bits_ranges=None, stark_cfg=None, witness_standin=None):
         """degree_bits: (legacy) fixed size of the aggregation / block circuits.  degree_bits_ranges: per table (lo, hi) half-open
         ranges of STARK sizes circuits exist for, like the reference's *_CIRCUIT_SIZE settings
         (/root/reference/common/src/prover_state/circuit.rs:76-100); None = every size."""
@@ -177,6 +179,11 @@ class SyntheticRecursion:
         self.cfg = cfg or standard_recursion_config()
         self.stark_cfg = stark_cfg or standard_fast_config()
         self.seed, self.shift = seed, size_shift
+        # per-proof witness generation on the CPU (stand-in, generate_witness_standin): ZK_WITNESS_STANDIN=0 / witness_standin=False keeps round 4's
+        # behaviour (one precomputed witness per circuit, no generator work inside the transaction)
+        self.witness_standin = os.environ.get("ZK_WITNESS_STANDIN", "1") != "0" if witness_standin is None else bool(witness_standin)
+        self.witness_standin_seconds, self.witness_standin_rows = 0.0, 0
+        self._standin_lock = threading.Lock()
         self.threshold = (self.THRESHOLD_DEGREE_BITS + size_shift) if threshold is None else threshold
         self.ranges = degree_bits_ranges
         self.fixed_bits = degree_bits
@@ -272,7 +279,35 @@ class SyntheticRecursion:
             self._pinned[k] = (ctx, buf)
         for i, col in enumerate(circ.pi_wires):
             buf[col, 0] = np.uint64(int(pih[i]))
+        if self.witness_standin:
+            self.generate_witness_standin(circ, buf)
         return buf
+
+    def generate_witness_standin(self, circ, buf):
+        """CPU stand-in for upstream's per-proof witness generation (plonky2 generate_partial_witness inside generate_txn_proof,
+        /root/reference/ops/src/lib.rs:52): the cells PoseidonGenerator / ArithmeticBaseGenerator produce are recomputed from the rows'
+        inputs by zk_host_plonk_witness_recompute, in the calling (proving) thread -- 3 us a PoseidonGate row, 8 ms for a 2^12-row
+        circuit, 70 ms for the 2^15-row root.  The witness satisfied its circuit, so nothing may change."""
+        from . import lib as zl, gates as GT
+        rows = getattr(circ, "_standin_rows", None)
+        if rows is None:
+            NS = len(GT.gate_program(circ.num_wires)[1])
+            cs = np.asarray(circ.constants)
+            pr = np.ascontiguousarray(circ.gate_rows["PoseidonGate"], dtype=np.uint32)
+            ar = np.ascontiguousarray(circ.gate_rows["ArithmeticGate"], dtype=np.uint32)
+            rows = circ._standin_rows = (pr, ar, np.ascontiguousarray(cs[NS][ar]), np.ascontiguousarray(cs[NS + 1][ar]))
+        pr, ar, c0, c1 = rows
+        L = zl.lib()
+        L.zk_host_plonk_witness_recompute.restype = C.c_int64
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        t0 = time.perf_counter()
+        changed = L.zk_host_plonk_witness_recompute(vp(buf), C.c_uint64(buf.shape[1]), C.c_uint32(buf.shape[0]), vp(pr), C.c_uint64(pr.size),
+                                                    vp(ar), vp(c0), vp(c1), C.c_uint64(ar.size))
+        if changed != 0:
+            raise RuntimeError("witness stand-in: %d cells changed (or error): the stand-in witness did not satisfy its gates" % changed)
+        with self._standin_lock:
+            self.witness_standin_seconds += time.perf_counter() - t0
+            self.witness_standin_rows += int(pr.size + ar.size)
 
     def job(self, ctx, kind, pubs, key=0, degree_bits=None):
         return self.state(ctx, kind, key, degree_bits), self.witness(ctx, kind, key, degree_bits, self.public_inputs_hash(ctx, pubs)), pubs

@@ -93,6 +93,7 @@ class Handoff:
         self.group = group if (group is not None or self.world == 1) else cached_host_group()
         self.res = [None] * n_units
         self.bytes, self.exposed_s, self.error = 0, 0.0, None
+        self._status = {}                        # rank dst: rank -> ok, from the ranks' closing markers
         self._q, self._th = queue.Queue(), None
         if self.world > 1:
             self._th = threading.Thread(target=self._recv_loop if self.rank == dst else self._send_loop, daemon=True)
@@ -106,6 +107,7 @@ class Handoff:
             self._q.put((unit, np.array(words, dtype=np.uint64, copy=True)))
 
     def _send_loop(self):
+        owed = None                              # words of a payload whose header went out: rank dst is (or will be) inside recv for exactly that many
         try:
             while True:
                 unit, w = self._q.get()          # (unit, words) or the marker (None, ok)
@@ -113,17 +115,23 @@ class Handoff:
                     dist.send(torch.tensor([-1, 0, 1 if w else 0], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
                     return
                 dist.send(torch.tensor([unit, w.size, 1], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
+                owed = w.size
                 dist.send(torch.from_numpy(w.view(np.int64)), self.dst, group=self.group, tag=self.PAY_TAG)
+                owed = None
         except Exception as e:          # surfaced by finish()
             self.error = e
-            try:        # rank dst counts markers: one more attempt to say "this rank is out" so that it is not left in recv
+            try:
+                # rank dst may be blocked in recv(PAY_TAG) for the payload whose header it has: give it that many words (zeros;
+                # the failure marker that follows voids the job), THEN the marker "this rank is out" that it counts
+                if owed is not None:
+                    dist.send(torch.zeros(owed, dtype=torch.int64), self.dst, group=self.group, tag=self.PAY_TAG)
                 dist.send(torch.tensor([-1, 0, 0], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
             except Exception:
                 pass    # transport gone: rank dst runs into the group's timeout (cached_host_group(timeout_s))
 
     def _recv_loop(self):
         try:
-            status, open_ranks = {}, self.world - 1
+            status, open_ranks = self._status, self.world - 1          # filled as markers arrive: a failing receiver still knows who reported what
             h = torch.zeros(3, dtype=torch.int64)
             while open_ranks:
                 r = dist.recv(h, group=self.group, tag=self.HDR_TAG)          # from whichever rank has something (gloo: any source)
@@ -136,7 +144,6 @@ class Handoff:
                 dist.recv(buf, src=r, group=self.group, tag=self.PAY_TAG)
                 self.res[unit] = buf.numpy().view(np.uint64)
                 self.bytes += 8 * n
-            self._status = status
         except Exception as e:
             self.error = e
 
@@ -157,7 +164,7 @@ class Handoff:
         # a failed receiver broadcasts 0; a worker with a failed sender has told rank dst so (marker with ok = 0) and still listens.
         flag = torch.tensor([1], dtype=torch.int64)
         if self.rank == self.dst:
-            status = getattr(self, "_status", {})
+            status = self._status
             bad = [r for r, s in status.items() if not s] + ([self.dst] if (not ok or self.error is not None) else [])
             missing = [u for u in range(self.n_units) if self.res[u] is None] if not bad else []
             flag[0] = 0 if (bad or missing) else 1

@@ -351,6 +351,12 @@ int32_t zk_prover_state_stats(uint64_t *compiled, uint64_t *loaded_from_disk);
  * table is read) are compiled by hiprtc for gfx950 and stored in the cache directory under the key a process on the target would look up.
  * gcn_arch_name: what hipGetDeviceProperties reports there ("gfx950:sramecc+:xnack-" on MI355X).  n_built / n_present (optional): files
  * written / found already there.  Kernels that were built with the library are skipped. */
+/* CPU stand-in for the witness generation of a recursion proof (host only, no context): recomputes, from their input cells, the cells that
+ * plonky2's PoseidonGenerator and ArithmeticBaseGenerator produce, for the given rows of a column-major num_wires x n witness in host
+ * memory -- the cost upstream pays per proof inside generate_txn_proof (/root/reference/ops/src/lib.rs:52).  Returns the number of cells
+ * whose value changed (0 for a witness that satisfied its circuit) or a negative ZK_ERR_*. */
+int64_t zk_host_plonk_witness_recompute(uint64_t *wires, uint64_t n, uint32_t num_wires, const uint32_t *poseidon_rows, uint64_t n_poseidon,
+                                        const uint32_t *arith_rows, const uint64_t *arith_c0, const uint64_t *arith_c1, uint64_t n_arith);
 int32_t zk_prover_state_build_offline(const zk_stark_config *cfg, uint32_t n_tables, const zk_table *tables, const char *gcn_arch_name,
                                       uint64_t *n_built, uint64_t *n_present);
 /* Build-time half of the same idea (upstream's constraints are Rust code monomorphised when the prover is built): the HIP source of

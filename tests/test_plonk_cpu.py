@@ -156,3 +156,42 @@ def test_oracle_prove_root_flow(orc):
     assert orc.verify_plonk(st, pubs, root) == 0
     other = pubs.copy(); other[3] ^= np.uint64(1)                  # another child digest: the root proof does not verify against it
     assert orc.verify_plonk(st, other, root) != 0
+
+
+def test_witness_generation_stand_in_reproduces_the_gate_cells(zk):
+    """zk_host_plonk_witness_recompute (VERDICT r4 #5b): the CPU stand-in for plonky2's per-proof witness generation recomputes the cells of
+    every PoseidonGate / ArithmeticGate row from the row's inputs (host code of the product library, no GPU).  On a witness that satisfies
+    its circuit nothing may change -- which also pins the C++ restatement of the gates' wire layout to gates.py (the one the oracle's
+    constraint program and the GPU prover share) -- and a corrupted INPUT cell must change the row's derived cells."""
+    import ctypes as C
+    from eth_tx_proof_amd import gates as GT, plonk
+    L = zk.lib()
+    L.zk_host_plonk_witness_recompute.restype = C.c_int64
+    circ, wires = plonk.recursion_circuit(9, seed=5)
+    n = 1 << 9
+    pr = np.ascontiguousarray(circ.gate_rows["PoseidonGate"], dtype=np.uint32)
+    ar = np.ascontiguousarray(circ.gate_rows["ArithmeticGate"], dtype=np.uint32)
+    NS = len(GT.gate_program(circ.num_wires)[1])
+    cs = np.asarray(circ.constants)
+    c0, c1 = np.ascontiguousarray(cs[NS][ar]), np.ascontiguousarray(cs[NS + 1][ar])
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run(w):
+        return L.zk_host_plonk_witness_recompute(vp(w), C.c_uint64(n), C.c_uint32(w.shape[0]), vp(pr), C.c_uint64(pr.size), vp(ar), vp(c0), vp(c1), C.c_uint64(ar.size))
+    w = wires.copy()
+    assert pr.size > 100 and ar.size > 20
+    assert run(w) == 0 and (w == wires).all()
+    bad = wires.copy()
+    bad[GT.PG_IN + 3, pr[7]] ^= np.uint64(1)
+    assert run(bad) > 50                                   # the whole permutation trace of that row moves
+    assert (bad[:, np.delete(np.arange(n), pr[7])] == wires[:, np.delete(np.arange(n), pr[7])]).all()
+    bad = wires.copy()
+    bad[1, ar[3]] ^= np.uint64(1)                          # a multiplicand of op 0: its output cell changes (the chain's later ops read their own cells)
+    assert run(bad) >= 1
+    assert run(wires.copy()[:100]) < 0                     # fewer than 135 wires: refused
+    # SyntheticRecursion runs it per proof and insists on "nothing changed"
+    rec = plonk.SyntheticRecursion(size_shift=-6, threshold=7, witness_standin=True)
+    circ2, w2 = rec.circuit("root")
+    buf = w2.copy()
+    rec.generate_witness_standin(circ2, buf)
+    assert (buf == w2).all() and rec.witness_standin_rows > 0
