@@ -64,6 +64,7 @@ def parse_args():
     return ap.parse_args()
 
 
+CPU_BASELINE_CACHES = [os.path.join(ROOT, "gpurun_out", ".cpu_baseline_cache.json"), "/tmp/zkgl_cpu_baseline_cache.json"]     # written by an N = 1 run, read by N > 1 runs
 PROVER_STATE_DIR = os.path.join(ROOT, "eth-tx-proof_amd", "prover_state")      # compiled constraint kernels of the wide tables (git-ignored *.co, travels with the tree)
 
 
@@ -717,7 +718,9 @@ def main():
         if world > 1:       # the only exchange of the job: finished proofs to rank 0, overlapped with proving (sharding.Handoff)
             line["per_rank"] = per_rank
             line["handoff"] = {"exposed_ms": handoff_timed["exposed_s"] * 1e3, "share_of_timed_region": handoff_timed["exposed_s"] / dt,
-                               "MB_into_rank0": handoff_timed["bytes"] / 1e6, "backend": "gloo host group, per-proof send from a background thread",
+                               "MB_into_rank0": handoff_timed["bytes"] / 1e6,
+                               "backend": ("RCCL default group (ZK_HANDOFF=rccl): ncclSend / ncclRecv of device tensors, rank 0 asks the ranks in turn" if os.environ.get("ZK_HANDOFF", "gloo").lower() == "rccl" and backend == "nccl"
+                                           else "gloo host group, per-proof send from a background thread (ZK_HANDOFF=rccl: the same over RCCL)"),
                                "note": "exposed = what rank 0 still waited for after its own last unit (last proofs in flight + one status broadcast)"}
         if rep:
             proofs0 = args.steps * args.inflight     # unit proofs this rank produced in the profiled region
@@ -819,11 +822,30 @@ def main():
         if gold and got != gold:
             print(json.dumps(line))
             sys.exit("bench.py: the proof of the timed region differs from the oracle's (sha256 %s != %s)" % (got, gold))
+        # cpu_baseline is MEASURED at N = 1 only (the contract); that run leaves its record in a small cache file, and the N > 1 runs of the
+        # same box (the driver runs N = 1, 2, 4, 8 back to back) carry it along, marked as cached
+        cache_key = "%s/2^%d x %d+%d" % (os.uname().nodename, args.log_n, C, args.helpers)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.log_n, C, args.helpers, check_proof=(timed_out0, pubs[0]))
             if line["cpu_baseline"]["timed_proof_verified"] is False:
                 print(json.dumps(line))
                 sys.exit("bench.py: the oracle's verifier rejects a proof of the timed region")
+            for path in CPU_BASELINE_CACHES:
+                try:
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    json.dump({"key": cache_key, "measured_unix": time.time(), "record": line["cpu_baseline"]}, open(path, "w"))
+                except OSError:
+                    pass
+        elif not args.no_cpu_baseline:
+            line["cpu_baseline"] = None
+            for path in CPU_BASELINE_CACHES:
+                try:
+                    c = json.load(open(path))
+                    if c.get("key") == cache_key:
+                        line["cpu_baseline"] = dict(c["record"], cached_from="the N = 1 run of this box %.0f s earlier (%s)" % (time.time() - c["measured_unix"], os.path.basename(path)))
+                        break
+                except (OSError, ValueError, KeyError):
+                    pass
         else:
             line["cpu_baseline"] = None
     for c in ctxs:

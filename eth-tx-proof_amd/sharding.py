@@ -84,12 +84,29 @@ class Handoff:
 
     HDR_TAG, PAY_TAG = 11, 12
 
-    def __init__(self, n_units, group=None, dst=0):
+    def __init__(self, n_units, group=None, dst=0, mode=None):
+        """mode (default: environment ZK_HANDOFF, else "gloo"):
+        "gloo"  -- the host (gloo) group, proofs travel as host buffers, rank dst receives from whichever rank has something;
+        "rccl"  -- opt-in (north_star's "RCCL only for the final hand-off over xGMI"): the job's DEFAULT process group (nccl =
+                   RCCL on GPUs) carries headers and payloads as device tensors, ncclSend / ncclRecv pairs.  RCCL has no receive from
+                   "any source", so rank dst asks the open ranks in turn for their next message (a rank's proofs arrive in its own order,
+                   ranks run at the same pace: the turn costs nothing while every rank has as many units).  The same ordered protocol
+                   runs over a gloo default group with host tensors -- that is how the CPU suite covers it; on hardware it has not run yet."""
+        import os
         import queue
         import threading
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.n_units, self.dst = n_units, dst
+        self.mode = (mode or os.environ.get("ZK_HANDOFF", "gloo")).lower()
+        if self.mode not in ("gloo", "rccl"):
+            raise ValueError("ZK_HANDOFF / mode must be gloo or rccl, not %r" % self.mode)
+        self.ordered = self.mode == "rccl" and self.world > 1
+        self.tdev = None                         # where the tensors of the ordered protocol live: the rank's GPU under nccl, the host under gloo
+        if self.ordered:
+            group = dist.group.WORLD
+            if dist.get_backend(group) == "nccl":
+                self.tdev = torch.device("cuda", torch.cuda.current_device())
         self.group = group if (group is not None or self.world == 1) else cached_host_group()
         self.res = [None] * n_units
         self.bytes, self.exposed_s, self.error = 0, 0.0, None
@@ -99,6 +116,17 @@ class Handoff:
             self._th = threading.Thread(target=self._recv_loop if self.rank == dst else self._send_loop, daemon=True)
             self._th.start()
 
+    # tensors of the wire: host tensors on the gloo group, device tensors on the RCCL group (tags are a gloo notion: RCCL pairs sends and
+    # receives of two ranks in program order, which the ordered protocol guarantees)
+    def _t(self, x):
+        return x if self.tdev is None else x.to(self.tdev)
+
+    def _send(self, t, tag):
+        if self.ordered:
+            dist.send(self._t(t), self.dst, group=self.group)
+        else:
+            dist.send(t, self.dst, group=self.group, tag=tag)
+
     def put(self, unit, words):
         """a finished proof (np.uint64 words) of unit `unit`; returns at once"""
         if self.world == 1 or self.rank == self.dst:
@@ -107,16 +135,18 @@ class Handoff:
             self._q.put((unit, np.array(words, dtype=np.uint64, copy=True)))
 
     def _send_loop(self):
+        if self.tdev is not None:
+            torch.cuda.set_device(self.tdev)
         owed = None                              # words of a payload whose header went out: rank dst is (or will be) inside recv for exactly that many
         try:
             while True:
                 unit, w = self._q.get()          # (unit, words) or the marker (None, ok)
                 if unit is None:
-                    dist.send(torch.tensor([-1, 0, 1 if w else 0], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
+                    self._send(torch.tensor([-1, 0, 1 if w else 0], dtype=torch.int64), self.HDR_TAG)
                     return
-                dist.send(torch.tensor([unit, w.size, 1], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
+                self._send(torch.tensor([unit, w.size, 1], dtype=torch.int64), self.HDR_TAG)
                 owed = w.size
-                dist.send(torch.from_numpy(w.view(np.int64)), self.dst, group=self.group, tag=self.PAY_TAG)
+                self._send(torch.from_numpy(w.view(np.int64)), self.PAY_TAG)
                 owed = None
         except Exception as e:          # surfaced by finish()
             self.error = e
@@ -124,12 +154,37 @@ class Handoff:
                 # rank dst may be blocked in recv(PAY_TAG) for the payload whose header it has: give it that many words (zeros;
                 # the failure marker that follows voids the job), THEN the marker "this rank is out" that it counts
                 if owed is not None:
-                    dist.send(torch.zeros(owed, dtype=torch.int64), self.dst, group=self.group, tag=self.PAY_TAG)
-                dist.send(torch.tensor([-1, 0, 0], dtype=torch.int64), self.dst, group=self.group, tag=self.HDR_TAG)
+                    self._send(torch.zeros(owed, dtype=torch.int64), self.PAY_TAG)
+                self._send(torch.tensor([-1, 0, 0], dtype=torch.int64), self.HDR_TAG)
             except Exception:
                 pass    # transport gone: rank dst runs into the group's timeout (cached_host_group(timeout_s))
 
+    def _recv_loop_ordered(self):
+        """rank dst under mode "rccl": the open ranks are asked in turn for their next message (header, then payload, from THAT rank)"""
+        try:
+            if self.tdev is not None:
+                torch.cuda.set_device(self.tdev)
+            status = self._status
+            open_ranks = [r for r in range(self.world) if r != self.dst]
+            while open_ranks:
+                for r in list(open_ranks):
+                    h = self._t(torch.zeros(3, dtype=torch.int64))
+                    dist.recv(h, src=r, group=self.group)
+                    unit, n, ok = (int(v) for v in h.cpu())
+                    if unit < 0:
+                        status[r] = ok
+                        open_ranks.remove(r)
+                        continue
+                    buf = self._t(torch.empty(n, dtype=torch.int64))
+                    dist.recv(buf, src=r, group=self.group)
+                    self.res[unit] = buf.cpu().numpy().view(np.uint64)
+                    self.bytes += 8 * n
+        except Exception as e:
+            self.error = e
+
     def _recv_loop(self):
+        if self.ordered:
+            return self._recv_loop_ordered()
         try:
             status, open_ranks = self._status, self.world - 1          # filled as markers arrive: a failing receiver still knows who reported what
             h = torch.zeros(3, dtype=torch.int64)
@@ -169,7 +224,9 @@ class Handoff:
             missing = [u for u in range(self.n_units) if self.res[u] is None] if not bad else []
             flag[0] = 0 if (bad or missing) else 1
         try:
+            flag = self._t(flag)
             dist.broadcast(flag, src=self.dst, group=self.group)
+            flag = flag.cpu()
         except Exception as e:
             raise HandoffError("proof hand-off failed: %s (status broadcast: %s)" % (self.error, e))
         if self.error is not None:

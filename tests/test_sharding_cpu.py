@@ -63,7 +63,7 @@ HANDOFF_WORKER = textwrap.dedent("""
     got = ho.finish(ok=True)
     if rank == 0:
         assert len(got) == n_units and all((got[u] == standin(u)).all() for u in range(n_units))
-        assert ho.bytes == sum(8 * standin(u).size for u in sharding.shard_units(n_units, world, 1))
+        assert ho.bytes == sum(8 * standin(u).size for r in range(1, world) for u in sharding.shard_units(n_units, world, r))
         assert ho.exposed_s < 0.04, ho.exposed_s    # the hand-off hid behind the proving
     else:
         assert got is None
@@ -95,6 +95,20 @@ def test_two_rank_overlapped_handoff_and_failure_propagation(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "HANDOFF_OK_0" in out.stdout and "HANDOFF_OK_1" in out.stdout
+
+
+def test_two_rank_ordered_handoff_the_rccl_protocol_over_gloo(tmp_path):
+    """ZK_HANDOFF=rccl (opt-in): headers and payloads over the job's DEFAULT group with source-specific receives -- the protocol RCCL's
+    send / recv pairs need (no receive from any source).  With a gloo default group the same code path runs on host tensors: the same
+    worker script as above must pass, proofs complete and in order, failure propagated to every rank."""
+    script = tmp_path / "handoff_worker_ordered.py"
+    script.write_text(HANDOFF_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", ZK_HANDOFF="rccl")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert all("HANDOFF_OK_%d" % r in out.stdout for r in range(3))
 
 
 def test_shard_units_cover_everything_once():

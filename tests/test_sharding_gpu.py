@@ -158,3 +158,27 @@ def test_bench_two_ranks_at_configs4_full_unit_size(tmp_path):
     if art:
         os.makedirs(art, exist_ok=True)
         open(os.path.join(art, "bench_2ranks_full_size_gloo_rehearsal.json"), "w").write(json.dumps(line) + "\n")
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_card_add_up_to_the_single_rank_rate(tmp_path):
+    """`--gpus 1` and the two-rank rehearsal must agree -- with the same number of units in flight on the card (4), one
+    rank with four workers and two ranks with two workers each do the same work on the same hardware, so the ranks' own proofs/s must
+    add up to the single rank's rate (within 20 %: two processes share the card's queues, not its arithmetic) and the whole-job value of
+    the two-rank line must be that sum.  Also: the N > 1 line carries the cpu_baseline record the N = 1 run cached, marked as cached."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--log-n", "18", "--no-pcie", "--no-profile", "--no-prove-root", "--no-log23"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--inflight", "4"] + common, capture_output=True, text=True, timeout=900, cwd=root)
+    assert one.returncode == 0, one.stderr[-3000:]
+    l1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert l1["cpu_baseline"] and "cached_from" not in l1["cpu_baseline"]
+    env = dict(os.environ, ZK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29703",
+                          os.path.join(root, "bench.py"), "--gpus", "2", "--inflight", "2"] + common, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert two.returncode == 0, two.stderr[-3000:]
+    l2 = json.loads(two.stdout.strip().splitlines()[-1])
+    per = [r["proofs_per_s"] for r in l2["per_rank"]]
+    assert len(per) == 2 and abs(sum(per) - l1["value"]) < 0.2 * l1["value"], (per, l1["value"])
+    assert abs(l2["value"] - sum(per)) < 0.15 * l2["value"], (l2["value"], per)          # max-over-ranks time against each rank's own clock
+    assert l2["cpu_baseline"] and "cached_from" in l2["cpu_baseline"] and l2["cpu_baseline"]["value"] == l1["cpu_baseline"]["value"]
