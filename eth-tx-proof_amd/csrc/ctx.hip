@@ -307,6 +307,26 @@ int32_t zk_ctx_create(int32_t device, void *stream, zk_ctx **out) {
     return ZK_OK;
 }
 
+int32_t zk_ctx_trim(zk_ctx *c, uint64_t *bytes_freed) {
+    if (!c) return ZK_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    if (c->wait_stream() != hipSuccess) return c->fail(ZK_ERR_HIP, "trim: stream");
+    uint64_t freed = 0;
+    // the big NTT pass tables first (keys start with the transform's log size, ntt_fast.hip pass_table): back to the free list ...
+    for (auto it = c->table_cache.begin(); it != c->table_cache.end();) {
+        const int k = atoi(it->first.c_str() + (it->first.compare(0, 3, "cs.") == 0 ? 3 : 0));
+        if (k > 24) { c->release(it->second); it = c->table_cache.erase(it); } else ++it;
+    }
+    // ... and the whole free list to the driver
+    if (!c->efence) {
+        for (auto &kv : c->free_blocks) { ZK_ALLOC_TRACE("free-dev-trim", kv.second, kv.first); hipFree(kv.second); c->block_size.erase(kv.second); c->bytes_allocated -= kv.first; freed += kv.first; }
+        c->free_blocks.clear();
+    }
+    if (c->side) { uint64_t f2 = 0; zk_ctx_trim(c->side, &f2); freed += f2; }
+    if (bytes_freed) *bytes_freed = freed;
+    return ZK_OK;
+}
+
 int32_t zk_ctx_set_side_commit(zk_ctx *c, int32_t on) {
     if (!c) return ZK_ERR_INVALID_ARG;
     c->side_commit = on ? 1 : 0;

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
     // fraction of an L1-hit global load's latency
     u64 *shRW = sh + NttGeom<ROW, W>::tile_elems;
     for (u32 i = tid0; i < (1u << W); i += 512) shRW[i] = RW[i];
+    // (Requesting the roots BEHIND the first tile's data loads -- so that a workgroup does not wait out an L2 round trip before it asks for
+    // its data -- was measured in round 5: 2-4 % SLOWER on all four passes of tools/ntt_floor.hip; the fill stays here.)
     // Persistent launch (round 5, p.n_blocks > 0): the grid is a fixed number of workgroups and workgroup b takes the tiles b, b + grid,
     // b + 2 grid, ... -- no wait for a tile's stores to drain and for the next workgroup to be set up between two tiles of a CU slot, the
     // roots are staged once.  grid % 8 == 0 keeps a workgroup's tiles on "its" XCD numbering (the pairing of col_fast == 2 holds).

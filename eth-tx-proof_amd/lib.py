@@ -96,6 +96,12 @@ class Context:
         """zk_ctx_set_side_commit: the widest table's trace commitment of a multi-table proof on a second stream (latency switch)"""
         self._chk(lib().zk_ctx_set_side_commit(self.h, C.c_int32(1 if on else 0)), "zk_ctx_set_side_commit")
 
+    def trim(self):
+        """zk_ctx_trim: cached device memory (free list, NTT tables of tall transforms) back to the driver; returns the bytes freed"""
+        n = C.c_uint64(0)
+        self._chk(lib().zk_ctx_trim(self.h, C.byref(n)), "zk_ctx_trim")
+        return n.value
+
     def set_host_transcript(self, on):
         """zk_ctx_set_host_transcript: the Fiat-Shamir sponge of this context's proofs on a host thread (latency switch; same proof words)"""
         self._chk(lib().zk_ctx_set_host_transcript(self.h, C.c_int32(1 if on else 0)), "zk_ctx_set_host_transcript")

@@ -74,6 +74,11 @@ int64_t zk_host_challenger_script(const int32_t *ops, uint32_t n_ops, const uint
  * a fault (returns 0 when the handler is registered). */
 int32_t zk_debug_fault_report(uint64_t addr);
 int32_t zk_ctx_synchronize(zk_ctx *ctx);
+/* Gives the context's CACHED device memory back to the driver: the free list of its block allocator (blocks are kept for reuse after a
+ * proof -- after a 2^26-row table that is tens of GB no other context of the process can get at) and the per-position NTT factor tables
+ * of transforms above 2^24 points (up to 2 GiB each; rebuilt on demand).  Waits for the stream first.  Live objects (batches, Plonk
+ * states, challengers) are untouched.  bytes_freed (optional): what went back. */
+int32_t zk_ctx_trim(zk_ctx *ctx, uint64_t *bytes_freed);
 const char *zk_last_error(zk_ctx *ctx);
 /* returns the hipStream_t the ctx enqueues on (for callers that record their own HIP events) */
 void *zk_ctx_stream(zk_ctx *ctx);

@@ -61,6 +61,8 @@ def test_tall_unit_proof_is_accepted_by_the_oracles_verifier_and_hashes_to_its_d
         proof = zl.prove_tables(ctx, cfg, [(prog, log_n, d, pub)])
     finally:
         ctx.dev_free(d)
+        freed = ctx.trim()                       # tens of GB of cached blocks and 2^26-entry NTT tables: the tests after this one create their own contexts
+    assert freed > (8 * n_cols << log_n), freed
     assert proof.size == orc.proof_size_words(cfg, [(prog, log_n, None, pub)])
     assert orc.verify(cfg, [(prog, log_n, None, pub)], proof) == 0, "the oracle's verifier rejects the GPU proof of the 2^%d x %d unit" % (log_n, n_cols)
     bad = proof.copy(); bad[proof.size // 2] ^= np.uint64(1)
