@@ -187,7 +187,9 @@ template <bool EXACT, int NC = 2> struct perm {
                 // see its "new" value) and nothing else can be given registers 12..15 before it; the first limb read is a compiler-made
                 // instruction, which hipcc holds back until the matrix instruction has written its result (an input-only
                 // operand ordered nothing).  tools/asm_clobber_audit.py --code checks the built code objects for the pattern.
-#ifndef PSDM_NO_RESULT_LIVENESS       // (defined by the negative control of tests/test_abi_cpu.py only: the round-4 defect, for the code-object audit to find)
+#if defined(PSDM_RESULT_LIVENESS_INPUT_ONLY)   // (tools/psdm_test.hip only: round 4's form, for an A/B of what the stronger statement costs)
+                asm volatile("" : : "v"(acc));
+#elif !defined(PSDM_NO_RESULT_LIVENESS)       // (defined by the negative control of tests/test_abi_cpu.py only: the round-4 defect, for the code-object audit to find)
                 asm volatile("" : "+v"(acc));
 #endif
             }

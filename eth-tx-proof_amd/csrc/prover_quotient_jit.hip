@@ -97,13 +97,22 @@ struct Gen {
 #define JIT_SEG_SLACK 192u       // = JIT_SEG / 4
 #define QJIT_FENCE 48u
 struct SegPlan { std::vector<u32> cut; std::vector<std::vector<u32>> live; u32 max_live = 0; };   // segment k = [cut[k], cut[k+1]); live[k]: registers alive at cut[k+1]
+// Which programs become a kernel SEQUENCE, and how long a piece is (round 5): a program of JIT_SEG_MIN instructions or more is cut into
+// pieces of at most JIT_SEG (the wide zkEVM tables: compile time, round 4); a MID-SIZE program -- JIT_SEG_MID_MIN .. JIT_SEG_MIN: the
+// 93-column bench AIR (844), the 71- and 165-column tables -- into pieces of at most JIT_SEG_MID.  Whole, those kernels take 217-249 vector
+// registers (two waves per SIMD) and are bound by memory latency: 1.69 ms alone, 3.6-4.5 ms beside the other streams of a bench step; as
+// three pieces of 96 / 150 / 108 registers the same work took 2.3-2.9 ms there (profiles/r05j_quotient_split.txt; 250, 300 and 350 tried,
+// 448 leaves a 258-register piece).  ZK_QJIT_SEG_MIN / ZK_QJIT_SEG: one threshold / one length for everything (experiments, tests).
+#define JIT_SEG_MID_MIN 640u
+#define JIT_SEG_MID 300u
 static u32 seg_min() {
-    static const u32 v = getenv("ZK_QJIT_SEG_MIN") ? (u32)atoi(getenv("ZK_QJIT_SEG_MIN")) : JIT_SEG_MIN;      // test / experiment switch
+    static const u32 v = getenv("ZK_QJIT_SEG_MIN") ? (u32)atoi(getenv("ZK_QJIT_SEG_MIN")) : JIT_SEG_MID_MIN;      // test / experiment switch
     return v;
 }
-static u32 seg_len() {
-    static const u32 v = getenv("ZK_QJIT_SEG") ? (u32)atoi(getenv("ZK_QJIT_SEG")) : JIT_SEG;                  // experiment switch
-    return v < 64 ? 64 : v;
+static u32 seg_len(const zk_air *air) {
+    static const u32 v = getenv("ZK_QJIT_SEG") ? (u32)atoi(getenv("ZK_QJIT_SEG")) : 0;                            // experiment switch
+    if (v) return v < 64 ? 64 : v;
+    return air->n_instrs >= JIT_SEG_MIN ? JIT_SEG : JIT_SEG_MID;
 }
 static SegPlan seg_plan(const zk_air *air, u32 seg, u32 slack) {
     const u32 n = air->n_instrs, NR = air->n_regs ? air->n_regs : 1;
@@ -155,7 +164,7 @@ static void emit_instr(Gen &g, const zk_instr &in, u32 nch) {
 // n_kernels / n_state: how many kernels the program becomes (names kname_0 .. kname_{n-1}) and how many state words per point ONE half
 // of the state buffer holds (accumulators + the most registers alive at a cut)
 static std::string generate_segmented(const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, const char *kname, bool standalone, u32 *n_kernels, u32 *n_state) {
-    const SegPlan pl = seg_plan(air, seg_len(), seg_len() / 4);
+    const SegPlan pl = seg_plan(air, seg_len(air), seg_len(air) / 4);
     const u32 K = (u32)pl.cut.size() - 1, NS = nch + pl.max_live, NR = air->n_regs ? air->n_regs : 1;
     if (n_kernels) *n_kernels = K;
     if (n_state) *n_state = NS;
@@ -484,9 +493,18 @@ static u64 fnv1a(const std::string &s) {
     return h;
 }
 // prover_quotient_aot.hip (generated by tools/gen_aot_quotient.py): kernels compiled with the library for the AIRs known at build time
-const void *zk_quotient_aot_lookup(u64 key_hash);
+struct QuotAotEntry { const void *const *fns; u32 n_kernels, n_state; };
+const QuotAotEntry *zk_quotient_aot_lookup(u64 key_hash);
 
 // The source of the constraint kernel of one AIR, for the build-time generator (host only, no GPU needed).
+static thread_local u32 g_last_source_kernels = 1, g_last_source_state = 0;
+// what the last zk_quotient_kernel_source of this thread generated: kernels of the sequence (names <name>_0 .. when more than one) and
+// state words per point and buffer half -- the build-time generator writes them into the registry
+extern "C" int32_t zk_quotient_kernel_source_plan(uint32_t *n_kernels, uint32_t *n_state) {
+    if (n_kernels) *n_kernels = g_last_source_kernels;
+    if (n_state) *n_state = g_last_source_state;
+    return ZK_OK;
+}
 extern "C" int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_challenges, uint32_t rate_bits, char *buf, size_t cap,
                                              size_t *len, uint64_t *key_hash) {
     if (!air || !len || !key_hash) return ZK_ERR_INVALID_ARG;
@@ -494,7 +512,7 @@ extern "C" int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_cha
     const u32 A = zk_air_n_aux(air, num_challenges);
     const u64 h = fnv1a(air_key(air, air->n_trace_cols, A, num_challenges, rate_bits));
     char name[64]; snprintf(name, sizeof name, "quotient_aot_%016llx", (unsigned long long)h);
-    std::string src = generate(air, air->n_trace_cols, A, num_challenges, rate_bits, name, false);
+    std::string src = generate(air, air->n_trace_cols, A, num_challenges, rate_bits, name, false, &g_last_source_kernels, &g_last_source_state);
     *len = src.size(); *key_hash = h;
     if (buf) { if (cap < src.size() + 1) return ZK_ERR_BUFFER_TOO_SMALL; memcpy(buf, src.c_str(), src.size() + 1); }
     return ZK_OK;
@@ -515,14 +533,28 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
 int32_t zk_quotient_jit_launch(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u32 rate_bits, QJitParams &p) {
     if (ctx->quotient_aot) {
         // a kernel for this very program was compiled with the library: an ordinary launch, no hiprtc, no module loading
-        if (const void *fn = zk_quotient_aot_lookup(fnv1a(air_key(air, C, A, nch, rate_bits)))) {
+        if (const QuotAotEntry *en = zk_quotient_aot_lookup(fnv1a(air_key(air, C, A, nch, rate_bits)))) {
+            // a sequence hands accumulators and live registers from kernel to kernel through a state buffer [half][slot][point], as below
+            u64 *state = nullptr;
+            if (en->n_kernels > 1) {
+                state = (u64 *)ctx->alloc((size_t)2 * en->n_state * p.L * sizeof(u64));
+                if (!state) return ZK_JIT_UNAVAILABLE;                  // the interpreter needs no such buffer
+            }
+            p.state = state;
             void *args[] = {&p};
-            hipError_t e;
+            hipError_t e = hipSuccess;
             // ZK_DEBUG_QSYNC (debugging aid, default 0): bit 0 = wait for the stream before the launch, bit 1 = after it
             static const int qsync = getenv("ZK_DEBUG_QSYNC") ? atoi(getenv("ZK_DEBUG_QSYNC")) : 0;
             if (qsync & 1) hipStreamSynchronize(ctx->stream);
-            { ProfScope ps(ctx, "quotient_eval"); e = hipLaunchKernel(fn, dim3((unsigned)((p.L + 255) / 256)), dim3(256), args, 0, ctx->stream); }
+            {
+                ProfScope ps(ctx, "quotient_eval");
+                for (u32 j = 0; j < en->n_kernels && e == hipSuccess; j++) {
+                    ctx->note_launch(j ? "quotient_eval(aot,k)" : "quotient_eval(aot,0)", (unsigned)((p.L + 255) / 256), 256);
+                    e = hipLaunchKernel(en->fns[j], dim3((unsigned)((p.L + 255) / 256)), dim3(256), args, 0, ctx->stream);
+                }
+            }
             if (qsync & 2) hipStreamSynchronize(ctx->stream);
+            ctx->release(state);                    // stream-ordered
             if (e != hipSuccess) return ctx->fail(ZK_ERR_HIP, "quotient aot: launch failed");
             return ZK_OK;
         }
@@ -739,9 +771,9 @@ static int32_t jit_get(zk_ctx *ctx, const zk_air *air, u32 C, u32 A, u32 nch, u3
     u32 K = 1, ns = 0;
     std::string key = air_key(air, C, A, nch, rate_bits);
     if (seg) {
-        const SegPlan pl = seg_plan(air, seg_len(), seg_len() / 4);         // the plan alone: cheap next to a compile
+        const SegPlan pl = seg_plan(air, seg_len(air), seg_len(air) / 4);   // the plan alone: cheap next to a compile
         K = (u32)pl.cut.size() - 1; ns = nch + pl.max_live;
-        const u32 hdr[4] = {0x53454751u /* "SEGQ" */, seg_len(), seg_len() / 4, QJIT_FENCE};
+        const u32 hdr[4] = {0x53454751u /* "SEGQ" */, seg_len(air), seg_len(air) / 4, QJIT_FENCE};
         key.append((const char *)hdr, sizeof hdr);
     }
     int32_t rc = jit_compile_cached(ctx, key, may_compile, [&]() { return generate(air, C, A, nch, rate_bits); }, seg ? "quotient_jit_0" : "quotient_jit", &z, k);
@@ -780,7 +812,7 @@ extern "C" int32_t zk_prover_state_build_offline(const zk_stark_config *cfg, uin
         if (zk_quotient_aot_lookup(fnv1a(air_key(air, C, A, nch, cfg->rate_bits)))) continue;
         std::string key = air_key(air, C, A, nch, cfg->rate_bits);
         if (air->n_instrs >= seg_min()) {                       // exactly jit_get's key of a kernel sequence
-            const u32 hdr[4] = {0x53454751u /* "SEGQ" */, seg_len(), seg_len() / 4, QJIT_FENCE};
+            const u32 hdr[4] = {0x53454751u /* "SEGQ" */, seg_len(air), seg_len(air) / 4, QJIT_FENCE};
             key.append((const char *)hdr, sizeof hdr);
         }
         const std::string disk_key = jit_disk_key(key, gcn_arch_name);

@@ -370,6 +370,9 @@ int32_t zk_prover_state_build_offline(const zk_stark_config *cfg, uint32_t n_tab
  * buf may be NULL to query the length. */
 int32_t zk_quotient_kernel_source(const zk_air *air, uint32_t num_challenges, uint32_t rate_bits, char *buf, size_t cap,
                                   size_t *len, uint64_t *key_hash);
+/* what the last zk_quotient_kernel_source call of this thread generated: the number of kernels (a program of 640 instructions or more becomes
+ * a SEQUENCE of call-free kernels <name>_0, <name>_1, ..) and the state words per point that one half of the sequence's hand-over buffer holds */
+int32_t zk_quotient_kernel_source_plan(uint32_t *n_kernels, uint32_t *n_state);
 /* ------------------------------------------------------------------ the pieces of a unit proof, one upstream item each
  * starky::lookup::lookup_helper_columns + cross_table_lookup::partial_sums: auxiliary columns of one table for the
  * challenges [beta_0, gamma_0, beta_1, gamma_1, ..] (host in, host out; aux_out = n_aux_cols x 2^log_n column-major,

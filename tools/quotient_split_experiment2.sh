@@ -1,0 +1,6 @@
+run() { echo "== $1"; shift; env "$@" python bench.py --steps 12 --warmup 3 --no-prove-root --no-log23 --no-cpu-baseline --no-pcie --no-live-pmc 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels_profiled_region']; a=d['kernels_one_unit_alone']
+print(round(d['value'],2),'proofs/s  quotient_eval region avg_ms',k.get('quotient_eval'),' alone',a.get('quotient_eval'), d['timed_proof_check']['identical_to_oracle'])"; }
+for s in 200 250 350; do run "seg $s" ZK_QUOTIENT_AOT=0 ZK_QJIT_SEG_MIN=800 ZK_QJIT_SEG=$s; done
+run "whole" X=1
+run "seg 300" ZK_QUOTIENT_AOT=0 ZK_QJIT_SEG_MIN=800 ZK_QJIT_SEG=300
