@@ -43,7 +43,16 @@ __device__ __forceinline__ psdm_v16i psdm_no_mfma(psdm_v4i a, psdm_v4i b, psdm_v
 #define PSDM_LDS_CMDS (PSDM_LDS_A)
 #define PSDM_LDS_CF (PSDM_LDS_CMDS + 8 * 4 * 2 * 4)
 #define PSDM_LDS_CG2 (PSDM_LDS_CF + 6 * 2 * 4)
-#define PSDM_LDS_V4 (PSDM_LDS_CG2 + 3 * 2 * 4)
+#define PSDM_LDS_V4_SMALL (PSDM_LDS_CG2 + 3 * 2 * 4)
+// PSDM_G2_LDS (round 5 experiment, VERDICT r4 #6a): the 27 KiB of operand fragments of the partial rounds' EXIT product (A_G2) live in the
+// workgroup's LDS image as well -- three 256-thread workgroups per CU hold 3 x 33 KiB -- so that the first-level cache only has to serve
+// the 33 KiB of A_F (it holds 32): a ds_read_b128 per fragment instead of a global load that misses about every second time.
+#ifdef PSDM_G2_LDS
+#define PSDM_LDS_AG2 PSDM_LDS_V4_SMALL
+#define PSDM_LDS_V4 (PSDM_LDS_V4_SMALL + 3 * 9 * 64)
+#else
+#define PSDM_LDS_V4 PSDM_LDS_V4_SMALL
+#endif
 
 namespace psdm {
 
@@ -57,7 +66,11 @@ __device__ __forceinline__ void lds_fill(const PsdmTables *T, psdm_v4i *sh) {
     for (u32 i = threadIdx.x; i < PSDM_LDS_A; i += blockDim.x) sh[i] = a[i];
     for (u32 i = threadIdx.x; i < PSDM_LDS_CF - PSDM_LDS_CMDS; i += blockDim.x) sh[PSDM_LDS_CMDS + i] = c0[i];
     for (u32 i = threadIdx.x; i < PSDM_LDS_CG2 - PSDM_LDS_CF; i += blockDim.x) sh[PSDM_LDS_CF + i] = c1[i];
-    for (u32 i = threadIdx.x; i < PSDM_LDS_V4 - PSDM_LDS_CG2; i += blockDim.x) sh[PSDM_LDS_CG2 + i] = c2[i];
+    for (u32 i = threadIdx.x; i < PSDM_LDS_V4_SMALL - PSDM_LDS_CG2; i += blockDim.x) sh[PSDM_LDS_CG2 + i] = c2[i];
+#ifdef PSDM_G2_LDS
+    const psdm_v4i *g2 = (const psdm_v4i *)&T->A_G2[0][0][0][0];
+    for (u32 i = threadIdx.x; i < 3 * 9 * 64; i += blockDim.x) sh[PSDM_LDS_AG2 + i] = g2[i];
+#endif
 }
 // pointer into the workgroup's LDS image, typed as such: a generic pointer makes hipcc read LDS with flat_load (aperture check,
 // both memory counters) instead of ds_read_b128 with an immediate offset
@@ -282,7 +295,11 @@ template <bool EXACT, int NC = 2> struct perm {
             psdm_v16i acc0 = cin, acc1 = cin;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
+#ifdef PSDM_G2_LDS
+                const psdm_v4i a = Alds[PSDM_LDS_AG2 + (t * 9 + k) * 64 + lane];
+#else
                 const psdm_v4i a = ld4(&T->A_G2[PSDM_AHOT(t)][PSDM_AHOT(k)][lane][0]);
+#endif
                 acc0 = PSDM_MFMA(a, k < 3 ? bs[0][k] : by[0][k - 3], acc0);
                 if (NC == 2) acc1 = PSDM_MFMA(a, k < 3 ? bs[NC - 1][k] : by[NC - 1][k - 3], acc1);
             }

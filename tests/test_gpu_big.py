@@ -42,7 +42,7 @@ def test_big_unit_proof_hashes_to_the_oracles_digest(ctx, ent):
 
 
 TALL = GOLD.get("tall_unit_proofs", [])
-TALL_SHAPES = [(24, 93, 19), (25, 21, 5), (26, 21, 5)]
+TALL_SHAPES = [(24, 93, 19), (25, 21, 5), (26, 21, 5), (25, 93, 19)]     # the last one: the top of the reference's default Cpu range, 215 GB on the card
 
 
 @pytest.mark.parametrize("log_n,n_cols,n_helpers", TALL_SHAPES, ids=lambda v: str(v))

@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc4
 rm -rf $OUT && mkdir -p $OUT
 cd $R
-BENCH="python3 bench.py --no-cpu-baseline --no-pcie --no-live-pmc --no-prove-root --steps 4"
+BENCH="python3 bench.py --no-cpu-baseline --no-pcie --no-live-pmc --no-prove-root --no-log23 --steps 4"
 for C in "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_INSTS_SALU"; do
     tag=$(echo $C | tr ' ' '+')
     echo "[pmc4] bench under $C" >&2
