@@ -154,9 +154,12 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
     const __attribute__((address_space(4))) PassParams &p = *kp;
     const int S = p.S;
     const size_t n = (size_t)1 << p.k;
-    size_t col = 0, base = 0, row0 = 0, rows_per_col = 1, total_rows = 0;
+    size_t rows_per_col = 1, total_rows = 0;
+    if (ROW) { rows_per_col = n >> W; total_rows = rows_per_col * ((size_t)p.n_cols << (CS ? p.cs_bits : 0)); }
+    // launch index -> the tile's place: (column, base position) of a TILE tile, first row of a ROW tile
+    auto tile_geom = [&](const u32 bid, size_t &col, size_t &base, size_t &row0) {
+    col = 0; base = 0; row0 = 0;
     if (ROW) {
-        rows_per_col = n >> W; total_rows = rows_per_col * ((size_t)p.n_cols << (CS ? p.cs_bits : 0));
         const u32 vcols = (u32)p.n_cols << (CS ? p.cs_bits : 0);
         if (p.col_fast) row0 = (size_t)(bid % vcols) * rows_per_col + ((size_t)(bid / vcols) << TL);
         else row0 = (size_t)bid << TL;
@@ -190,6 +193,9 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
         else { col = bid / tiles_per_col; rem = bid % tiles_per_col; }
         base = ((rem / tiles_per_block) << (W + S)) + ((rem % tiles_per_block) << TL);
     }
+    };
+    size_t col, base, row0;
+    tile_geom(bid, col, base, row0);
     // ROW tiles: 2^P3 padding elements after every block of R = 2^(W-4) slots (instead of an XOR swizzle): the M-phase lanes, which
     // walk slots R apart, then spread over the LDS banks, and -- unlike an XOR -- the padded index of register q is the thread's
     // base plus a compile-time constant in all three mappings, so an exchange costs no address arithmetic per element.
