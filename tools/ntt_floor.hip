@@ -46,32 +46,34 @@ static float run(const PassParams &p, int reps, hipStream_t st) {
 int main(int argc, char **argv) {
     const int n_cols = argc > 1 ? atoi(argv[1]) : 93, reps = argc > 2 ? atoi(argv[2]) : 20, col_group = argc > 3 ? atoi(argv[3]) : 0;
     g_persist = argc > 4 ? atoi(argv[4]) : 0;
+    const size_t pad = argc > 5 ? (size_t)atol(argv[5]) : 0;       // column stride = n + pad elements (are power-of-two strides a channel hot spot?)
     const int k = 20;
     const size_t n = (size_t)1 << k;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const double simds = 4.0 * prop.multiProcessorCount, ghz = prop.clockRate * 1e-6;
     u64 *in, *mid, *out, *tab, *rw;
-    CK(hipMalloc(&in, n * n_cols * 8)); CK(hipMalloc(&mid, n * n_cols * 8)); CK(hipMalloc(&out, 2 * n * n_cols * 8));
+    const size_t cs = n + pad;
+    CK(hipMalloc(&in, cs * n_cols * 8)); CK(hipMalloc(&mid, cs * n_cols * 8)); CK(hipMalloc(&out, 2 * cs * n_cols * 8));
     CK(hipMalloc(&tab, n * 8)); CK(hipMalloc(&rw, 1024 * 8));
     // random canonical field elements everywhere: on zeros (or on values made from addresses) the weak arithmetic meets its
     // rare-repair paths -- and the exact redo -- far more often than on real data
-    fill_random<<<4096, 256>>>(in, n * n_cols, 1); fill_random<<<4096, 256>>>(mid, n * n_cols, 2);
+    fill_random<<<4096, 256>>>(in, cs * n_cols, 1); fill_random<<<4096, 256>>>(mid, cs * n_cols, 2);
     fill_random<<<1024, 256>>>(tab, n, 3); fill_random<<<4, 256>>>(rw, 1024, 4);
     CK(hipDeviceSynchronize());
     hipStream_t st; CK(hipStreamCreate(&st));
     PassParams b = {};
     b.k = k; b.W = 10; b.TL = 3; b.n_cols = n_cols; b.tw_full = rw; b.col_group = col_group; b.load_tab_mask = b.store_tab_mask = ~0u;
     struct { const char *name; float ms; } res[4];
-    { PassParams p = b; p.in = in; p.in_stride = n; p.out = mid; p.out_stride = n; p.S = 10; p.inverse = 1; p.canon_in = 1; p.store_tab = tab; p.col_fast = 2;
+    { PassParams p = b; p.in = in; p.in_stride = cs; p.out = mid; p.out_stride = cs; p.S = 10; p.inverse = 1; p.canon_in = 1; p.store_tab = tab; p.col_fast = 2;
       res[0] = {"inverse DIF pass 1 (TILE, inter-pass factors at the store)", run<false, false, true>(p, reps, st)}; }
-    { PassParams p = b; p.in = mid; p.in_stride = n; p.out = mid; p.out_stride = n; p.S = 0; p.inverse = 1; p.store_tab = tab; p.col_fast = 1;
+    { PassParams p = b; p.in = mid; p.in_stride = cs; p.out = mid; p.out_stride = cs; p.S = 0; p.inverse = 1; p.store_tab = tab; p.col_fast = 1;
       res[1] = {"inverse DIF pass 2 (ROW, 1/n at the store)", run<false, true, true>(p, reps, st)}; }
-    { PassParams p = b; p.in = mid; p.in_stride = n; p.out = in; p.out_stride = n; p.S = 0; p.load_tab = tab; p.col_fast = 1;
+    { PassParams p = b; p.in = mid; p.in_stride = cs; p.out = in; p.out_stride = cs; p.S = 0; p.load_tab = tab; p.col_fast = 1;
       res[2] = {"forward DIT pass 1 (ROW, coset factors at the load)", run<true, true, false>(p, reps, st)}; }
-    { PassParams p = b; p.in = in; p.in_stride = n; p.out = out; p.out_stride = 2 * n; p.S = 10; p.load_tab = tab; p.permute_out = 1; p.col_fast = 2;
+    { PassParams p = b; p.in = in; p.in_stride = cs; p.out = out; p.out_stride = 2 * cs; p.S = 10; p.load_tab = tab; p.permute_out = 1; p.col_fast = 2;
       res[3] = {"forward DIT pass 2 (TILE, inter-pass factors at the load, permuted store)", run<true, false, false>(p, reps, st)}; }
     CK(hipStreamSynchronize(st));
-    printf("# ntt_floor mode %d: %d columns x 2^%d, W = 10, col_group %d, persist %d, %d SIMDs at %.2f GHz, %d launches each\n", (int)NTT_FLOOR, n_cols, k, col_group, g_persist, (int)simds, ghz, reps);
+    printf("# ntt_floor mode %d: %d columns x 2^%d, W = 10, col_group %d, persist %d, stride pad %zu, %d SIMDs at %.2f GHz, %d launches each\n", (int)NTT_FLOOR, n_cols, k, col_group, g_persist, pad, (int)simds, ghz, reps);
     const double elems = (double)n * n_cols;
     for (auto &r : res)
         printf("%-78s %8.1f us  %6.3f ns/element  %6.2f SIMD-cycles/element  %7.1f GB/s algorithmic\n", r.name, r.ms * 1e3, r.ms * 1e6 / elems,
