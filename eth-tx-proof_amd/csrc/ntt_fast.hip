@@ -116,6 +116,9 @@ bool zk_ntt_fast_pass(zk_ctx *ctx, const PassParams &p0, bool dit, bool row, con
             if (((T * st + (((size_t)1 << p.cs_bits) - 1) * sub + ((size_t)1 << p.W)) >> 29) != 0) return false;
         }
     }
+    // passes that move more than the Infinity Cache holds write whole lines with the non-temporal hint (kernel: ntt_st)
+    static const int use_nt = getenv("ZK_NTT_NT") ? atoi(getenv("ZK_NTT_NT")) : 1;
+    p.nt_store = (use_nt && ((((size_t)1 << p.k) * vcols * sizeof(u64)) >> 29) != 0) ? 1u : 0u;
     bool cf_on = row ? (use_colfast & 1) : (use_colfast & 2);
     p.col_fast = cf_on ? (row ? (rows_per_col >= ((size_t)1 << p.TL) ? 1 : 0) : 1) : 0;
     if (!row && p.col_fast) {

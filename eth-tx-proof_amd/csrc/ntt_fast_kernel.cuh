@@ -81,20 +81,34 @@ __device__ __forceinline__ u64 ntt_uniform(u64 v) {
 #ifndef NTT_FLOOR
 #define NTT_FLOOR 0
 #endif
+// NTT_NT (experiment): 1 = the pass's data stores carry the non-temporal hint (written once, read by a later kernel: keep them out of the way
+// of the half-used input lines that the paired workgroup of a TILE pass still needs from L2), 2 = its data loads as well
+#ifndef NTT_NT
+#define NTT_NT 0
+#endif
 __device__ __forceinline__ u64 ntt_ld(const u64 *sbase, u32 thr_bytes) {
     const u64 b = ntt_uniform((u64)sbase);
-#if NTT_FLOOR
+#if NTT_FLOOR && NTT_FLOOR != 3      // (3: real loads, no stores; 4: made-up loads, real stores -- which side of the traffic is exposed?)
     return ((b + thr_bytes) * 0x9E3779B97F4A7C15ull) >> 1;     // a well-mixed value below 2^63 (structured values meet the rare-repair paths far too often)
+#else
+#if NTT_NT >= 2
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) u64 *)(b + thr_bytes));
 #else
     return *(const __attribute__((address_space(1))) u64 *)(b + thr_bytes);
 #endif
+#endif
 }
-__device__ __forceinline__ void ntt_st(u64 *sbase, u32 thr_bytes, u64 v) {
+__device__ __forceinline__ void ntt_st(u64 *sbase, u32 thr_bytes, u64 v, bool nt = false) {
     const u64 b = ntt_uniform((u64)sbase);
-#if NTT_FLOOR
+#if NTT_FLOOR && NTT_FLOOR != 4
     if (v != 0x5A5A5A5A5A5A5A5Aull) return;
 #endif
-    *(__attribute__((address_space(1))) u64 *)(b + thr_bytes) = v;
+    // nt (wave-uniform): whole-line stores of a pass over far more data than the caches hold go out with the non-temporal hint -- they are
+    // read again only by a later kernel, and they no longer push the lines other workgroups still read out of L2 (round 5: -1.5...-2.5 % on
+    // the ROW passes and on the permuted row store at 93 x 2^20; NOT for the 64-byte runs of a plain TILE store, which must meet their
+    // other half in L2: +3 % there; profiles/r05r_ntt_nontemporal.txt)
+    if (nt || NTT_NT >= 1) __builtin_nontemporal_store(v, (__attribute__((address_space(1))) u64 *)(b + thr_bytes));
+    else *(__attribute__((address_space(1))) u64 *)(b + thr_bytes) = v;
 }
 
 template <bool DIT, bool ROW, int W, bool INV, bool CS = false>
@@ -292,13 +306,13 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
 
     // everything from the global loads to the last butterfly, for either arithmetic (glx<false> fast / glx<true> exact)
     auto to_lds = [&](int m) {
-        if (act && NTT_FLOOR < 2) {
+        if (act && NTT_FLOOR != 2) {
 #pragma unroll
             for (int q = 0; q < 16; q++) { u32 t, slot; map_any(m, q, t, slot); sh[lds_idx(t, slot)] = x[q]; }
         }
     };
     auto from_lds = [&](int m) {
-        if (act && NTT_FLOOR < 2) {
+        if (act && NTT_FLOOR != 2) {
 #pragma unroll
             for (int q = 0; q < 16; q++) { u32 t, slot; map_any(m, q, t, slot); x[q] = sh[lds_idx(t, slot)]; }
         }
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
                 if (ROW) ub = modeB ? col_off((size_t)row032 + t_uni, p.out_stride, p.out_sub) + pe_uni
                                     : col_off(vcolA, p.out_stride, p.out_sub) + ((rr0 + t_uni) << W) + pe_uni;
                 else ub = col_off(vcolA, p.out_stride, p.out_sub) + ((bitrev_u32(inner0, S) + bitrev_u32(t_uni, S)) << W) + pe_uni;
-                ntt_st(p.out + ub, sc_thr, v);
+                ntt_st(p.out + ub, sc_thr, v, p.nt_store != 0);
             }
         }
         continue;
@@ -530,7 +544,7 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 if (!(st_lim > (int)GM::t_uni(SMAP, q))) continue;
-                ntt_st(p.out + uni_off(1, SMAP, q), st_thr, need_mul ? f[q] : x[q]);
+                ntt_st(p.out + uni_off(1, SMAP, q), st_thr, need_mul ? f[q] : x[q], ROW && p.nt_store != 0);
             }
         }
     };

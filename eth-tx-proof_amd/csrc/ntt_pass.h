@@ -31,6 +31,7 @@ struct PassParams {
     // and the kernel reduces the tile's base position by this mask before it indexes the table (all ones: the table covers the column)
     unsigned load_tab_mask, store_tab_mask;
     u64 store_const;                // multiply every stored element by this constant instead of a table (0: none)
+    unsigned nt_store;              // whole-line data stores with the non-temporal hint (set by the launcher for passes over more data than the caches hold)
     unsigned n_blocks;              // register-radix kernel, persistent launch: number of tiles (0: one workgroup per tile, the grid says it)
 };
 

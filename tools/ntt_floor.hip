@@ -8,7 +8,7 @@
 // pass's own occupancy (two 512-thread workgroups per CU): its run time is the floor no memory-side change can go below; mode 1 adds
 // what the LDS exchanges and their barriers cost; mode 0 - mode 1 is what the pass waits for HBM.
 // Build (three binaries, one per mode):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -DNTT_FLOOR=<m> -Ieth-tx-proof_amd/csrc tools/ntt_floor.hip -o tools/bin/ntt_floor<m>
-// Run:  tools/bin/ntt_floor<m> [n_cols=93] [reps=20] [col_group=0]      -> one line per pass: us per launch, ns per element, SIMD-cycles per element
+// Run:  tools/bin/ntt_floor<m> [n_cols=93] [reps=20] [col_group=0] [persist=0] [stride_pad=0] [nt_store=1]      -> one line per pass: us per launch, ns per element, SIMD-cycles per element
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -46,6 +46,7 @@ static float run(const PassParams &p, int reps, hipStream_t st) {
 int main(int argc, char **argv) {
     const int n_cols = argc > 1 ? atoi(argv[1]) : 93, reps = argc > 2 ? atoi(argv[2]) : 20, col_group = argc > 3 ? atoi(argv[3]) : 0;
     g_persist = argc > 4 ? atoi(argv[4]) : 0;
+    const unsigned nt_store = argc > 6 ? (unsigned)atoi(argv[6]) : 1;      // whole-line stores with the non-temporal hint (the library sets it for big passes)
     const size_t pad = argc > 5 ? (size_t)atol(argv[5]) : 0;       // column stride = n + pad elements (are power-of-two strides a channel hot spot?)
     const int k = 20;
     const size_t n = (size_t)1 << k;
@@ -62,7 +63,7 @@ int main(int argc, char **argv) {
     CK(hipDeviceSynchronize());
     hipStream_t st; CK(hipStreamCreate(&st));
     PassParams b = {};
-    b.k = k; b.W = 10; b.TL = 3; b.n_cols = n_cols; b.tw_full = rw; b.col_group = col_group; b.load_tab_mask = b.store_tab_mask = ~0u;
+    b.k = k; b.W = 10; b.TL = 3; b.n_cols = n_cols; b.tw_full = rw; b.col_group = col_group; b.load_tab_mask = b.store_tab_mask = ~0u; b.nt_store = nt_store;
     struct { const char *name; float ms; } res[4];
     { PassParams p = b; p.in = in; p.in_stride = cs; p.out = mid; p.out_stride = cs; p.S = 10; p.inverse = 1; p.canon_in = 1; p.store_tab = tab; p.col_fast = 2;
       res[0] = {"inverse DIF pass 1 (TILE, inter-pass factors at the store)", run<false, false, true>(p, reps, st)}; }
@@ -73,7 +74,7 @@ int main(int argc, char **argv) {
     { PassParams p = b; p.in = in; p.in_stride = cs; p.out = out; p.out_stride = 2 * cs; p.S = 10; p.load_tab = tab; p.permute_out = 1; p.col_fast = 2;
       res[3] = {"forward DIT pass 2 (TILE, inter-pass factors at the load, permuted store)", run<true, false, false>(p, reps, st)}; }
     CK(hipStreamSynchronize(st));
-    printf("# ntt_floor mode %d: %d columns x 2^%d, W = 10, col_group %d, persist %d, stride pad %zu, %d SIMDs at %.2f GHz, %d launches each\n", (int)NTT_FLOOR, n_cols, k, col_group, g_persist, pad, (int)simds, ghz, reps);
+    printf("# ntt_floor mode %d: %d columns x 2^%d, W = 10, col_group %d, persist %d, stride pad %zu, nt stores %u, %d SIMDs at %.2f GHz, %d launches each\n", (int)NTT_FLOOR, n_cols, k, col_group, g_persist, pad, nt_store, (int)simds, ghz, reps);
     const double elems = (double)n * n_cols;
     for (auto &r : res)
         printf("%-78s %8.1f us  %6.3f ns/element  %6.2f SIMD-cycles/element  %7.1f GB/s algorithmic\n", r.name, r.ms * 1e3, r.ms * 1e6 / elems,
