@@ -468,3 +468,32 @@ def test_fault_recorder_names_the_owner_of_an_address(zk, capfd):
         c.dev_free(d)
     finally:
         c.close()
+
+
+def test_ntt_persistent_tile_loop_gives_the_same_commitment(orc):
+    """ZK_NTT_PERSIST (opt-in, measured slower: DESIGN.md section 8): a fixed grid of workgroups walking the tiles of a pass -- the tile loop
+    is in every register-radix kernel, so it must be exact when switched on: a 2^17 x 5 commit (two passes each way, 80 tiles per pass over a
+    grid of 16) in a child process against the oracle's cap and opened rows, forced exact redo included."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import eth_tx_proof_amd
+from eth_tx_proof_amd import lib as zl
+import orc
+rng = np.random.default_rng(9)
+v = rng.integers(0, 0xFFFFFFFF00000001, size=(5, 1 << 17), dtype=np.uint64)
+o = orc.Batch(v, rate_bits=1, cap_height=4)
+c = zl.Context(0)
+b = c.batch_from_values(v, rate_bits=1, cap_height=4)
+assert (b.cap == o.cap).all()
+for i in (0, 77, (1 << 18) - 1):
+    assert (b.prove(i) == o.prove(i)).all()
+f = c.ntt(v[:2]); assert (f == orc.fft(v[:2])).all() and (c.ntt(f, inverse=True) == v[:2]).all()
+print("PERSIST_OK")
+''' % (root, os.path.join(root, "oracle"))
+    for extra in ({}, {"ZK_FORCE_EXACT_REDO": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZK_NTT_PERSIST="16", **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "PERSIST_OK" in r.stdout, r.stderr[-3000:]
