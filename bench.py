@@ -509,6 +509,9 @@ def main():
     from eth_tx_proof_amd import air, lib as zl, sharding
 
     world = int(env_world or "1")
+    # ZK_BENCH_FORCE_DIST=1: the process group, barrier, max-over-ranks reduction and the hand-off objects of the N > 1 path also at N = 1 --
+    # the RCCL (nccl) branch then runs on ONE card (tests/test_sharding_gpu.py): the closest rehearsal of it that a single-GPU box allows
+    use_dist = world > 1 or bool(os.environ.get("ZK_BENCH_FORCE_DIST"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # one rank per GPU over RCCL.  ZK_BENCH_BACKEND=gloo is a REHEARSAL switch: it lets several ranks share one card (RCCL refuses
@@ -516,7 +519,7 @@ def main():
     backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local = local % max(1, torch.cuda.device_count())
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # finished proofs are host buffers: they are handed to rank 0 over a gloo group.  gloo prints its connection report on
         # stdout from C++ (so does the rehearsal's gloo default group): keep it away from the ONE JSON line this program owes its caller
@@ -582,7 +585,7 @@ def main():
         timed region, as the contract says, not around each step.  N > 1: the finished proofs travel to rank 0 (where
         leader.ProverInput.prove folds them) WHILE the next units are proved; what is left at the end -- the last proofs in flight and one
         status broadcast -- is `handoff.exposed_s`."""
-        ho = sharding.Handoff(k * args.inflight * world, group=host_pg) if world > 1 else None
+        ho = sharding.Handoff(k * args.inflight * world, group=host_pg) if use_dist else None
         th = [threading.Thread(target=work, args=(s, k, ho)) for s in range(args.inflight)]
         t_own = time.perf_counter()
         for t in th:
@@ -599,7 +602,7 @@ def main():
             raise errors[0]
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -609,7 +612,7 @@ def main():
         run_steps(k)
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else None)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -629,7 +632,7 @@ def main():
     handoff_timed = dict(handoff)
     # every rank's own rate over the timed region (an imbalance between GPUs shows here before it shows in the job's aggregate)
     per_rank = None
-    if world > 1:
+    if use_dist:
         mine = {"rank": rank, "units": args.steps * args.inflight, "proving_s": own["proving_s"], "proofs_per_s": args.steps * args.inflight / own["proving_s"],
                 "device": torch.cuda.get_device_name(dev) if torch.cuda.is_available() else None}
         per_rank = [None] * world
@@ -726,7 +729,7 @@ def main():
             "value_profiled": (units / dt_prof) if dt_prof else None,
             "value_pcie_inclusive": pcie,
         }
-        if world > 1:       # the only exchange of the job: finished proofs to rank 0, overlapped with proving (sharding.Handoff)
+        if use_dist:       # the only exchange of the job: finished proofs to rank 0, overlapped with proving (sharding.Handoff)
             line["per_rank"] = per_rank
             line["handoff"] = {"exposed_ms": handoff_timed["exposed_s"] * 1e3, "share_of_timed_region": handoff_timed["exposed_s"] / dt,
                                "MB_into_rank0": handoff_timed["bytes"] / 1e6,
@@ -875,7 +878,7 @@ def main():
             sys.exit("bench.py: the 2^23-row unit's proof differs from the oracle's committed digest")
         if isinstance(line.get("prove_root"), dict) and (line["prove_root"].get("timed_proof_check") or {}).get("identical_to_oracle") is False:
             sys.exit("bench.py: the transaction's proofs differ from the oracle's committed digests")
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
