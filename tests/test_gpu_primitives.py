@@ -50,7 +50,7 @@ def test_merkle_build(ctx, orc, L, ll, ch):
     assert (cap == ocap).all() and (dig == odig).all()
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 10, 11, 12, 13, 16, 20, 21])
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 9, 10, 11, 12, 13, 16, 18, 19, 20, 21])
 def test_ntt_forward_inverse_coset(ctx, orc, log_n):
     rng = np.random.default_rng(100 + log_n)
     ncols = 3 if log_n <= 16 else 2
@@ -146,7 +146,8 @@ def test_ntt_linearity_full_size(ctx):
     assert (ctx.ntt(fs, inverse=True) == s).all()
 
 
-@pytest.mark.parametrize("log_n,ncols,cap_h", [(3, 1, 0), (4, 5, 2), (6, 9, 4), (10, 3, 4), (11, 8, 4), (12, 17, 4), (13, 93, 4), (7, 135, 4), (5, 4, 4), (9, 2, 4)])
+@pytest.mark.parametrize("log_n,ncols,cap_h", [(3, 1, 0), (4, 5, 2), (6, 9, 4), (10, 3, 4), (11, 8, 4), (12, 17, 4), (13, 93, 4), (7, 135, 4), (5, 4, 4), (9, 2, 4),
+                                               (18, 3, 4), (19, 2, 4)])       # 9 + 9 and 10 + 9 bits: the W = 9 ROW passes with shift twiddles (round 5)
 def test_batch_from_values(ctx, orc, log_n, ncols, cap_h):
     rng = np.random.default_rng(log_n * 100 + ncols)
     vals = field_rand(rng, (ncols, 1 << log_n))
