@@ -40,14 +40,22 @@ template <bool ROW, int W> struct NttGeom {
     // W = 9, 10: the M and L phases together are a 2^(4+P3) <= 64-point transform, whose root w_32 = 2^6 / w_64 = 2^3 is a power of two:
     // the twiddle between the two phases is a SHIFT, by an amount that depends on the register (compile time) and on the P3 low slot
     // bits -- which the M mapping of these widths takes from the WAVE number, so that the amount is uniform per wave (round 5)
-    // (W = 9 TILE tiles keep the general products: with sixteen adjacent positions per slot their kernels were at the 128-register limit
-    // already, and the shift form spilled 6-9 registers to scratch there)
-    static constexpr bool SH64 = NTT_SH64 && (P2 == 4) && (P3 == 2 || (P3 == 1 && ROW));
+    // (W = 9 TILE tiles spilled 6-9 registers with the shift form until the exchange indices were spelled out as thread base + constant,
+    // lds_off below: that freed ~20 registers in every instantiation)
+    static constexpr bool SH64 = NTT_SH64 && (P2 == 4) && (P3 == 2 || P3 == 1);
     // LDS image of the tile.  ROW: row stride RS; SH64 tiles pad one element per 32 slots (+1 per row at W = 10), the others 2^P3 per
     // 2^(W-4) slots.  TILE: element (t, slot) at slot * T + t; SH64 tiles skip T elements after every 2^(W-4) slots.  With these every
     // exchange of the SH64 mappings is free of bank conflicts on ds_read_b64 (32-lane groups, 64 banks) except the TILE L reads.
     static constexpr int RS = !ROW ? 0 : SH64 ? (1 << W) + (1 << (W - 5)) + (W == 10 ? 1 : 0) : (1 << W) + (W >= 8 ? (16 << P3) : 0);
     static constexpr size_t tile_elems = ROW ? ((size_t)RS << TL) : ((size_t)((1 << W) + (SH64 ? 16 : 0)) << TL);
+    // index of element (t, slot) in the LDS image.  ADDITIVE over disjoint bit fields of (t, slot): the index of register q's element is
+    // the index of the thread's part plus lds_idx(t_uni, slot_uni) of the register's part -- a compile-time constant (lds_off below)
+    static constexpr u32 lds_idx(u32 t, u32 slot) {
+        if (SH64) return ROW ? t * (u32)RS + slot + (slot >> 5) : ((slot + (slot >> (W - 4))) << TL) + t;
+        if (ROW) return W >= 8 ? t * (u32)RS + slot + ((slot >> (W - 4)) << P3) : (t << W) + slot;
+        return (slot << TL) + t;
+    }
+    static constexpr u32 lds_off(int m, int q) { return lds_idx(t_uni(m, q), slot_uni(m, q)); }
     // the part of (t, slot) of mapping m (0 = H, 1 = M, 2 = L) that register q contributes; map_X(q) = map_X(0) + these
     static constexpr u32 t_uni(int m, int q) {
         if (!ROW || m == 0) return 0;
@@ -213,11 +221,7 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
     // ROW tiles: 2^P3 padding elements after every block of R = 2^(W-4) slots (instead of an XOR swizzle): the M-phase lanes, which
     // walk slots R apart, then spread over the LDS banks, and -- unlike an XOR -- the padded index of register q is the thread's
     // base plus a compile-time constant in all three mappings, so an exchange costs no address arithmetic per element.
-    auto lds_idx = [&](u32 t, u32 slot) -> u32 {
-        if (SH64) return ROW ? t * (u32)RS + slot + (slot >> 5) : ((slot + (slot >> (W - 4))) << TL) + t;
-        if (ROW) return SWZ ? t * (u32)RS + slot + ((slot >> (W - 4)) << P3) : (t << W) + slot;
-        return (slot << TL) + t;
-    };
+    auto lds_idx = [&](u32 t, u32 slot) -> u32 { return NttGeom<ROW, W>::lds_idx(t, slot); };
     // SH64: the low slot bits of the M mapping, uniform per wave (a scalar: the shift twiddles branch on it)
     u32 wave_id = wave_id0;
     asm volatile("" : "+s"(wave_id));                                 // opaque per tile, like tid: nothing derived from it is kept across the loop
@@ -307,14 +311,20 @@ __global__ __launch_bounds__(512, 4) void ntt_fast_kernel(PassParams p_arg) {
     // everything from the global loads to the last butterfly, for either arithmetic (glx<false> fast / glx<true> exact)
     auto to_lds = [&](int m) {
         if (act && NTT_FLOOR != 2) {
+            // thread part once + a constant per register (round 5: spelled out -- with the one-pad-per-32-slots image hipcc no longer found
+            // the split by itself and spent four vector instructions per element and exchange on the index)
+            u32 t0, s0; map_any(m, 0, t0, s0);
+            const u32 b = lds_idx(t0, s0);
 #pragma unroll
-            for (int q = 0; q < 16; q++) { u32 t, slot; map_any(m, q, t, slot); sh[lds_idx(t, slot)] = x[q]; }
+            for (int q = 0; q < 16; q++) sh[b + NttGeom<ROW, W>::lds_off(m, q)] = x[q];
         }
     };
     auto from_lds = [&](int m) {
         if (act && NTT_FLOOR != 2) {
+            u32 t0, s0; map_any(m, 0, t0, s0);
+            const u32 b = lds_idx(t0, s0);
 #pragma unroll
-            for (int q = 0; q < 16; q++) { u32 t, slot; map_any(m, q, t, slot); x[q] = sh[lds_idx(t, slot)]; }
+            for (int q = 0; q < 16; q++) x[q] = sh[b + NttGeom<ROW, W>::lds_off(m, q)];
         }
     };
 
