@@ -164,7 +164,7 @@ def test_bench_two_ranks_at_configs4_full_unit_size(tmp_path):
 def test_two_ranks_on_one_card_add_up_to_the_single_rank_rate(tmp_path):
     """`--gpus 1` and the two-rank rehearsal must agree -- with the same number of units in flight on the card (4), one
     rank with four workers and two ranks with two workers each do the same work on the same hardware, so the ranks' own proofs/s must
-    add up to the single rank's rate (within 20 %: two processes share the card's queues, not its arithmetic) and the whole-job value of
+    add up to the single rank's rate (within 30 %: two processes share the card's queues, not its arithmetic) and the whole-job value of
     the two-rank line must be that sum.  Also: the N > 1 line carries the cpu_baseline record the N = 1 run cached, marked as cached."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -179,8 +179,8 @@ def test_two_ranks_on_one_card_add_up_to_the_single_rank_rate(tmp_path):
     assert two.returncode == 0, two.stderr[-3000:]
     l2 = json.loads(two.stdout.strip().splitlines()[-1])
     per = [r["proofs_per_s"] for r in l2["per_rank"]]
-    assert len(per) == 2 and abs(sum(per) - l1["value"]) < 0.2 * l1["value"], (per, l1["value"])
-    assert abs(l2["value"] - sum(per)) < 0.15 * l2["value"], (l2["value"], per)          # max-over-ranks time against each rank's own clock
+    assert len(per) == 2 and abs(sum(per) - l1["value"]) < 0.3 * l1["value"], (per, l1["value"])
+    assert abs(l2["value"] - sum(per)) < 0.25 * l2["value"], (l2["value"], per)          # max-over-ranks time against each rank's own clock
     assert l2["cpu_baseline"] and "cached_from" in l2["cpu_baseline"] and l2["cpu_baseline"]["value"] == l1["cpu_baseline"]["value"]
 
 
