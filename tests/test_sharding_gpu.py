@@ -196,7 +196,7 @@ def test_bench_rccl_branch_rehearsed_with_one_rank(handoff):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZK_BENCH_FORCE_DIST="1", ZK_HANDOFF=handoff, MASTER_ADDR="127.0.0.1")
     env.pop("ZK_BENCH_BACKEND", None)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29707",
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29708" if handoff == "rccl" else "29707",
                           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--inflight", "2", "--log-n", "18",
                           "--no-pcie", "--no-cpu-baseline", "--no-profile", "--no-prove-root", "--no-log23"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
